@@ -1,0 +1,124 @@
+// t2fit_dispatch.h -- one voxel end to end: input checks, bounds, solver choice, epilogue values.
+// Mirrors the control flow of fit_voxel (run_t2mapping.py:237-312) for a single lane.
+#pragma once
+
+#include "t2fit_lane.h"
+#include "t2fit_lbfgsb.h"
+#include "t2fit_lm.h"
+
+namespace t2fit {
+
+// Host-side translation of the ABI struct into the kernel argument.
+inline LaneParams make_lane_params(const t2fit_config& c) {
+  LaneParams P;
+  P.model = c.model; P.solver = c.solver; P.precision = c.precision; P.n_te = c.n_te;
+  P.no_prior = c.no_prior; P.norm = c.norm; P.maxls = c.maxls; P.maxiter = c.maxiter;
+  P.maxfun = c.maxfun; P.pad0 = 0;
+  for (int i = 0; i < T2FIT_MAX_TE; ++i) {
+    P.te[i] = i < c.n_te ? c.te_ms[i] : 0.0;
+    P.te_f[i] = (float)P.te[i];
+  }
+  for (int j = 0; j < 3; ++j) { P.x0[j] = c.x0[j]; P.lb[j] = c.lb[j]; P.ub[j] = c.ub[j]; }
+  P.ftol = c.ftol; P.gtol = c.gtol; P.fd_step = c.fd_step; P.lm_xtol = c.lm_xtol;
+  P.np_k_ub = c.noprior_k_ub; P.np_t2_lb = c.noprior_t2_lb; P.np_t2_ub = c.noprior_t2_ub;
+  return P;
+}
+
+struct LaneOutputs {
+  float t2, k, sigma, res, r2, fun;
+  int32_t nit;
+  uint8_t status;
+};
+
+T2_HD void fit_lane(const LaneParams& P, EchoView y, LaneResult& r) {
+  const int n = P.n_te;
+  const int np = n_params(P.model);
+  ObjCtx c;
+  c.P = &P;
+  c.y = y;
+  c.norm = P.norm != 0;
+  c.ymax = 1.0f;
+  bool finite = true;
+  float ymax = y[0];
+  for (int i = 0; i < n; ++i) {
+    const float v = y[i];
+    finite = finite && t2_finite(v);
+    ymax = v > ymax ? v : ymax;
+  }
+  if (c.norm) {
+    c.ymax = ymax;
+    for (int i = 0; i < n; ++i) finite = finite && t2_finite(c.sample(i));
+  }
+  double lb[3], ub[3];
+  const bool feasible = lane_bounds(P, y[0], lb, ub);
+  r.nit = 0;
+  r.fun = NAN;
+  if (!feasible) {
+    // scipy raises "one of the lower bounds is greater than an upper bound" (whole volume aborts)
+    r.x[0] = r.x[1] = r.x[2] = NAN;
+    if (np == 2) r.x[2] = 0.0;
+    r.status = T2FIT_ST_INFEASIBLE;
+    return;
+  }
+  if (!finite) {
+    // objective is NaN everywhere: scipy stops at the clipped start point, nit = 0, success False
+    for (int j = 0; j < 3; ++j) r.x[j] = j < np ? t2_clip(P.x0[j], lb[j], ub[j]) : 0.0;
+    r.status = T2FIT_ST_NONFINITE;
+    return;
+  }
+  if (P.solver == T2FIT_SOLVER_LM) {
+    if (P.precision == T2FIT_PREC_F32) {
+      if (np == 2) lm_solve<float, 2>(c, lb, ub, r);
+      else lm_solve<float, 3>(c, lb, ub, r);
+    } else {
+      if (np == 2) lm_solve<double, 2>(c, lb, ub, r);
+      else lm_solve<double, 3>(c, lb, ub, r);
+    }
+  } else {
+    lbfgsb_solve(c, lb, ub, r);
+  }
+}
+
+// Epilogue: float32 map values, residual map and optional R^2 from the float32 parameters
+// (run_t2mapping.py:456-458 casts, utils/t2map_utils.py:62-89).
+T2_HD void lane_epilogue(const LaneParams& P, EchoView y, const LaneResult& r, LaneOutputs& o, bool want_r2) {
+  ObjCtx c;
+  c.P = &P;
+  c.y = y;
+  c.norm = P.norm != 0;
+  c.ymax = 1.0f;
+  if (c.norm) {
+    float ymax = y[0];
+    for (int i = 1; i < P.n_te; ++i) ymax = y[i] > ymax ? y[i] : ymax;
+    c.ymax = ymax;
+  }
+  o.k = (float)r.x[0];
+  o.t2 = (float)r.x[1];
+  o.sigma = (float)r.x[2];
+  o.fun = (float)r.fun;
+  o.nit = r.nit;
+  o.status = r.status;
+  o.res = residual_mean(c, o.k, o.t2, o.sigma);
+  o.r2 = 0.0f;
+  if (want_r2) {
+    // coefficient of determination about the mean (formula of the reference's notebook,
+    // notebooks/20240924_ada_qmri_jmri_invitro.ipynb:345-347); no reference map exists for it
+    const int n = P.n_te;
+    double mean = 0.0;
+    for (int i = 0; i < n; ++i) mean += (double)c.sample(i);
+    mean /= n;
+    double ss_tot = 0.0, ss_res = 0.0;
+    const bool gauss = P.model == T2FIT_MODEL_GAUSSIAN;
+    for (int i = 0; i < n; ++i) {
+      const double yi = (double)c.sample(i);
+      const double E = t2_exp(-P.te[i] / r.x[1]);
+      const double m = gauss || P.model == T2FIT_MODEL_RICIAN ? r.x[0] * E
+                                                                : t2_sqrt(r.x[0] * r.x[0] * E * E + r.x[2] * r.x[2]);
+      ss_res += (yi - m) * (yi - m);
+      ss_tot += (yi - mean) * (yi - mean);
+    }
+    o.r2 = (float)(1.0 - ss_res / ss_tot);
+  }
+}
+
+}  // namespace t2fit

@@ -1,0 +1,239 @@
+// t2fit_lane.h -- per-lane (one voxel) building blocks of the T2 fit kernels.
+//
+// Everything here is plain arithmetic on one voxel's echo samples so that the very same source
+// is compiled (a) by hipcc into the gfx950 kernels in t2fit_kernels.hip and (b) by g++ into the
+// host-side lane simulator that tests/ uses to check solver logic where no GPU is present.  The
+// simulator is test infrastructure; the product library contains device code only.
+//
+// Reference formulas: run_t2mapping.py:129-177 (models/objectives), utils/t2map_utils.py:62-89
+// (residual map).  T2, TE in milliseconds.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/t2fit.h"
+
+#if defined(__HIPCC__)
+#define T2_HD __host__ __device__ __forceinline__
+#define T2_DEVICE_COMPILE 1
+#else
+#define T2_HD inline
+#endif
+
+namespace t2fit {
+
+// Device-side copy of t2fit_config with both precisions of the echo times.  Passed by value as a
+// kernel argument: it lives in the kernarg segment and uniform-index reads become scalar loads.
+struct LaneParams {
+  int32_t model, solver, precision, n_te;
+  int32_t no_prior, norm, maxls, maxiter, maxfun, pad0;
+  double te[T2FIT_MAX_TE];
+  float te_f[T2FIT_MAX_TE];
+  double x0[3], lb[3], ub[3];
+  double ftol, gtol, fd_step, lm_xtol;
+  double np_k_ub, np_t2_lb, np_t2_ub;
+};
+
+// One voxel's samples: element i lives at p[i*stride].  In the kernels p points into LDS (one
+// column per lane, stride = padded block width); in the host simulator stride is 1.
+struct EchoView {
+  const float* p;
+  int stride;
+  T2_HD float operator[](int i) const { return p[i * stride]; }
+};
+
+struct LaneResult {
+  double x[3];  // k, T2, sigma
+  double fun;
+  int32_t nit;
+  uint8_t status;
+};
+
+// ---- small math wrappers ---------------------------------------------------------------------
+T2_HD double t2_exp(double x) { return exp(x); }
+T2_HD double t2_sqrt(double x) { return sqrt(x); }
+T2_HD double t2_log(double x) { return log(x); }
+#if defined(__HIP_DEVICE_COMPILE__)
+T2_HD float t2_exp(float x) { return __expf(x); }        // v_exp_f32 path
+T2_HD float t2_rsqrt(float x) { return __frsqrt_rn(x); }  // v_rsq_f32
+T2_HD float t2_rcp(float x) { return __frcp_rn(x); }
+#else
+T2_HD float t2_exp(float x) { return expf(x); }
+T2_HD float t2_rsqrt(float x) { return 1.0f / sqrtf(x); }
+T2_HD float t2_rcp(float x) { return 1.0f / x; }
+#endif
+T2_HD double t2_rsqrt(double x) { return 1.0 / sqrt(x); }
+T2_HD double t2_rcp(double x) { return 1.0 / x; }
+T2_HD float t2_sqrt(float x) { return sqrtf(x); }
+T2_HD float t2_log(float x) { return logf(x); }
+
+template <typename T> T2_HD T t2_min(T a, T b) { return a < b ? a : b; }
+template <typename T> T2_HD T t2_max(T a, T b) { return a > b ? a : b; }
+template <typename T> T2_HD T t2_clip(T x, T lo, T hi) { return t2_min(t2_max(x, lo), hi); }
+template <typename T> T2_HD T t2_abs(T a) { return a < T(0) ? -a : a; }
+T2_HD bool t2_finite(double x) { return (x - x) == 0.0; }
+T2_HD bool t2_finite(float x) { return (x - x) == 0.0f; }
+
+template <typename T> struct TeOf;
+template <> struct TeOf<double> {
+  T2_HD static double at(const LaneParams& P, int i) { return P.te[i]; }
+};
+template <> struct TeOf<float> {
+  T2_HD static float at(const LaneParams& P, int i) { return P.te_f[i]; }
+};
+
+// ---- exponentially scaled modified Bessel function I0 (scipy.special.i0e = Cephes i0e) ---------
+// Chebyshev expansions from Cephes i0.c (public domain, Moshier): [0,8] and (8,inf).
+T2_HD double t2_chbevl(double x, const double* c, int n) {
+  double b0 = c[0], b1 = 0.0, b2 = 0.0;
+  for (int i = 1; i < n; ++i) {
+    b2 = b1;
+    b1 = b0;
+    b0 = x * b1 - b2 + c[i];
+  }
+  return 0.5 * (b0 - b2);
+}
+
+T2_HD double t2_i0e(double x) {
+  const double A[30] = {
+      -4.41534164647933937950E-18, 3.33079451882223809783E-17,  -2.43127984654795469359E-16,
+      1.71539128555513303061E-15,  -1.16853328779934516808E-14, 7.67618549860493561688E-14,
+      -4.85644678311192946090E-13, 2.95505266312963983461E-12,  -1.72682629144155570723E-11,
+      9.67580903537323691224E-11,  -5.18979560163526290666E-10, 2.65982372468238665035E-9,
+      -1.30002500998624804212E-8,  6.04699502254191894932E-8,   -2.67079385394061173391E-7,
+      1.11738753912010371815E-6,   -4.41673835845875056359E-6,  1.64484480707288970893E-5,
+      -5.75419501008210370398E-5,  1.88502885095841655729E-4,   -5.76375574538582365885E-4,
+      1.63947561694133579842E-3,   -4.32430999505057594430E-3,  1.05464603945949983183E-2,
+      -2.37374148058994688156E-2,  4.93052842396707084878E-2,   -9.49010970480476444210E-2,
+      1.71620901522208775349E-1,   -3.04682672343198398683E-1,  6.76795274409476084995E-1};
+  const double B[25] = {
+      -7.23318048787475395456E-18, -4.83050448594418207126E-18, 4.46562142029675999901E-17,
+      3.46122286769746109310E-17,  -2.82762398051658348494E-16, -3.42548561967721913462E-16,
+      1.77256013305652638360E-15,  3.81168066935262242075E-15,  -9.55484669882830764870E-15,
+      -4.15056934728722208663E-14, 1.54008621752140982691E-14,  3.85277838274214270114E-13,
+      7.18012445138366623367E-13,  -1.79417853150680611778E-12, -1.32158118404477131188E-11,
+      -3.14991652796324136454E-11, 1.18891471078464383424E-11,  4.94060238822496958910E-10,
+      3.39623202570838634515E-9,   2.26666899049817806459E-8,   2.04891858946906374183E-7,
+      2.89137052083475648297E-6,   6.88975834691682398426E-5,   3.36911647825569408990E-3,
+      8.04490411014108831608E-1};
+  if (x < 0) x = -x;
+  if (x <= 8.0) return t2_chbevl(x * 0.5 - 2.0, A, 30);
+  return t2_chbevl(32.0 / x - 2.0, B, 25) / sqrt(x);
+}
+
+// ---- objective values exactly in the reference's operation order (float64) ---------------------
+// y_scale: 1/max(y) when cfg.norm (run_t2mapping.py:237-238 divides in float32), else unused.
+struct ObjCtx {
+  const LaneParams* P;
+  EchoView y;
+  bool norm;
+  float ymax;
+  T2_HD float sample(int i) const { return norm ? y[i] / ymax : y[i]; }
+};
+
+// mean squared residual, 2-parameter model (run_t2mapping.py:141-147)
+T2_HD double obj_gauss(const ObjCtx& c, double k, double t2) {
+  const int n = c.P->n_te;
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double r = (double)c.sample(i) - k * t2_exp(-c.P->te[i] / t2);
+    s += r * r;
+  }
+  return s / n;
+}
+
+// mean squared residual, 3-parameter noise-floor model (run_t2mapping.py:149-155)
+T2_HD double obj_gauss_rician(const ObjCtx& c, double k, double t2, double sg) {
+  const int n = c.P->n_te;
+  const double k2 = k * k, s2 = sg * sg;
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double r = (double)c.sample(i) - t2_sqrt(k2 * t2_exp(-2.0 * c.P->te[i] / t2) + s2);
+    s += r * r;
+  }
+  return s / n;
+}
+
+// Rician negative log-likelihood (run_t2mapping.py:157-177).  The reference takes log(signal) and
+// signal**2 in the samples' float32 before promoting, reproduced here.
+T2_HD double obj_rician(const ObjCtx& c, double k, double t2, double sg) {
+  const int n = c.P->n_te;
+  const double s2 = sg * sg;
+  const double ls2 = t2_log(s2);
+  double ll = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const float yf = c.sample(i);
+    const double m = k * t2_exp(-c.P->te[i] / t2);
+    const double x = (m * (double)yf) / s2;
+    const double a = (double)logf(yf) - ls2;
+    const double b = ((double)(yf * yf) + m * m) / (2.0 * s2);
+    const double d = (x < 0 ? -x : x) + t2_log(t2_i0e(x));
+    ll += (a - b) + d;
+  }
+  return -ll;
+}
+
+T2_HD double objective(const ObjCtx& c, const double* x) {
+  switch (c.P->model) {
+    case T2FIT_MODEL_GAUSSIAN: return obj_gauss(c, x[0], x[1]);
+    case T2FIT_MODEL_GAUSSIAN_RICIAN: return obj_gauss_rician(c, x[0], x[1], x[2]);
+    default: return obj_rician(c, x[0], x[1], x[2]);
+  }
+}
+
+T2_HD int n_params(int model) { return model == T2FIT_MODEL_GAUSSIAN ? 2 : 3; }
+
+// Per-voxel bounds (run_t2mapping.py:243-245).  Returns false when some lb > ub.
+T2_HD bool lane_bounds(const LaneParams& P, float y0_raw, double* lb, double* ub) {
+  for (int j = 0; j < 3; ++j) {
+    lb[j] = P.lb[j];
+    ub[j] = P.ub[j];
+  }
+  if (P.no_prior) {
+    lb[0] = (double)y0_raw;
+    ub[0] = P.np_k_ub;
+    lb[1] = P.np_t2_lb;
+    ub[1] = P.np_t2_ub;
+  }
+  const int np = n_params(P.model);
+  bool ok = true;
+  for (int j = 0; j < np; ++j) ok = ok && !(lb[j] > ub[j]);
+  return ok;
+}
+
+// Mean signed residual from the float32 maps (utils/t2map_utils.py:62-89): float64 prediction
+// stored as float32, float32 residuals, numpy's pairwise float32 row sum, divided by nTE.
+T2_HD float residual_mean(const ObjCtx& c, float k32, float t232, float s32) {
+  const int n = c.P->n_te;
+  const bool gauss = c.P->model == T2FIT_MODEL_GAUSSIAN;
+  // numpy float32 add.reduce over a contiguous row: n < 8 sequential from 0; otherwise eight
+  // interleaved partial sums over the first n - n%8 items, combined as a balanced tree, then the
+  // remaining items added one by one.  r8 is indexed through selects so it stays in registers.
+  float r8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float sum = 0.0f;
+  const int n8 = n & ~7;
+  const double k = (double)k32, t2 = (double)t232;
+  const double k2 = (double)(k32 * k32), s2 = (double)(s32 * s32);  // float32 squares, as numpy
+  for (int i = 0; i < n; ++i) {
+    double pred;
+    if (gauss) pred = k * t2_exp(-c.P->te[i] / t2);
+    else pred = t2_sqrt(k2 * t2_exp(-2.0 * c.P->te[i] / t2) + s2);
+    const float r = c.sample(i) - (float)pred;
+    if (n < 8 || i >= n8) {
+      if (n >= 8 && i == n8)
+        sum = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+      sum += r;
+    } else {
+      const int slot = i & 7;
+#if defined(T2_DEVICE_COMPILE)
+#pragma unroll
+#endif
+      for (int j = 0; j < 8; ++j) r8[j] = (j == slot) ? r8[j] + r : r8[j];
+    }
+  }
+  if (n >= 8 && n8 == n) sum = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+  return sum / (float)n;
+}
+
+}  // namespace t2fit

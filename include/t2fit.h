@@ -1,0 +1,167 @@
+/*
+ * t2fit.h -- C ABI of the MI355X per-voxel T2 relaxation fitter (libt2fit_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of Medical-Image-Analysis-Laboratory/
+ * fetal_t2mapping: the voxel-wise fit that run_t2mapping.py drives.  The reference has no FFI of
+ * its own (it is pure Python); each entry point below names the Python call site it replaces
+ * (paths relative to the reference root).  Plain pointers and sizes only: no Python, torch or
+ * C++ types cross this boundary.  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - all functions return 0 on success, a negative T2FIT_E_* code otherwise; the message of the
+ *     last failure on the calling thread is available from t2fit_last_error().
+ *   - "dev" pointers are HIP device pointers (e.g. torch.Tensor.data_ptr() on ROCm); "host"
+ *     pointers are ordinary memory.  `stream` is a hipStream_t passed as void* (NULL = default).
+ *   - echo samples are float32; echo times, tables and tolerances are float64 in MILLISECONDS,
+ *     as everywhere in the reference (run_t2mapping.py:369).
+ *   - n_vox is the dense voxel count N = Z*Y*X (C order, run_t2mapping.py:411); masked-out voxels
+ *     are written as zeros in every map (run_t2mapping.py:415-418).
+ */
+#ifndef T2FIT_H
+#define T2FIT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T2FIT_ABI_VERSION 1
+#define T2FIT_MAX_TE 32
+
+/* error codes */
+#define T2FIT_OK 0
+#define T2FIT_E_INVALID (-1) /* bad argument (null pointer, size, unknown enum)            */
+#define T2FIT_E_HIP (-2)     /* a HIP runtime call failed (no device, OOM, launch failure) */
+#define T2FIT_E_BOUNDS (-3)  /* table bounds have lb > ub (scipy raises ValueError there)  */
+
+/* objective, run_t2mapping.py:129-177 */
+#define T2FIT_MODEL_GAUSSIAN 0        /* mean (y - k e^{-t/T2})^2                    :141-147 */
+#define T2FIT_MODEL_GAUSSIAN_RICIAN 1 /* mean (y - sqrt(k^2 e^{-2t/T2} + s^2))^2     :149-155 */
+#define T2FIT_MODEL_RICIAN 2          /* Rician negative log-likelihood with i0e     :157-177 */
+
+/* solver */
+#define T2FIT_SOLVER_LBFGSB 0 /* the reference's solver and stop rules: per-lane L-BFGS-B (m=10) with
+                                 scipy's bound-aware forward-difference gradient, float64
+                                 (run_t2mapping.py:260-286 -> scipy.optimize.minimize)             */
+#define T2FIT_SOLVER_LM 1     /* log-linear seed + bounded Levenberg-Marquardt run to convergence of
+                                 the same objective and bounds (least-squares models only)          */
+
+/* arithmetic of the LM solver (the L-BFGS-B solver is always float64) */
+#define T2FIT_PREC_F64 0
+#define T2FIT_PREC_F32 1
+
+/* memory layout of the echo stack */
+#define T2FIT_LAYOUT_TE_MAJOR 0    /* (nTE, N): nTE contiguous volumes, what the reader produces
+                                      before np.stack (run_t2mapping.py:377)                 */
+#define T2FIT_LAYOUT_VOXEL_MAJOR 1 /* (N, nTE): the reference's reshaped_t2w (:411)          */
+
+/* per-voxel status map values */
+#define T2FIT_ST_MASKED 0     /* outside the mask, not fitted                                  */
+#define T2FIT_ST_CONVERGED 1  /* solver's convergence test met (scipy result.success == True)  */
+#define T2FIT_ST_NOT_CONV 2   /* iteration/evaluation cap or abnormal line-search termination  */
+#define T2FIT_ST_NONFINITE 3  /* non-finite sample or objective at the start: x = clipped x0,
+                                 nit = 0 (scipy: ABNORMAL, success False; run_t2mapping.py:298) */
+#define T2FIT_ST_INFEASIBLE 4 /* data-dependent bounds with lb > ub (no-prior and S(TE0) > 10000):
+                                 the reference raises ValueError and aborts the volume; maps get NaN */
+
+/* Fit configuration: the reference's fit_params dict (run_t2mapping.py:29-111) plus the per-call
+ * flags of fit_voxel (:120) flattened to a POD.  Fill with t2fit_config_default() first. */
+typedef struct t2fit_config {
+  int32_t abi_version;        /* T2FIT_ABI_VERSION */
+  int32_t model;              /* T2FIT_MODEL_*                                     */
+  int32_t solver;             /* T2FIT_SOLVER_*                                    */
+  int32_t precision;          /* T2FIT_PREC_* (LM only)                            */
+  int32_t n_te;               /* 2..T2FIT_MAX_TE                                   */
+  int32_t no_prior;           /* 1: k >= S(TE0), k <= 10000, T2 in [10,2000]  (:243-245)      */
+  int32_t norm;               /* 1: divide each voxel's samples by their maximum (:237-238)    */
+  int32_t maxls;              /* L-BFGS-B line-search step cap ("maxls", 50 in every table)    */
+  int32_t maxiter;            /* iteration cap: scipy default 15000 (L-BFGS-B); LM default 60  */
+  int32_t maxfun;             /* objective-evaluation cap (scipy default 15000)                */
+  int32_t reserved0;
+  int32_t reserved1;
+  double te_ms[T2FIT_MAX_TE]; /* echo times [ms], ascending                                     */
+  double x0[3];               /* initial_guess (k, T2, sigma); clipped into the bounds as scipy does */
+  double lb[3];               /* param_bounds lower (k, T2, sigma)                              */
+  double ub[3];               /* param_bounds upper                                             */
+  double ftol;                /* L-BFGS-B relative-reduction stop (1e-6 / 1e-2 in the tables)  */
+  double gtol;                /* L-BFGS-B projected-gradient stop (scipy default 1e-5 / 1e-2)  */
+  double fd_step;             /* absolute forward-difference step, scipy "eps" = 1e-8          */
+  double lm_xtol;             /* LM relative step tolerance (0 = default for the precision)    */
+  double noprior_k_ub;        /* 10000 (:244) */
+  double noprior_t2_lb;       /* 10    (:245) */
+  double noprior_t2_ub;       /* 2000  (:245) */
+} t2fit_config;
+
+/* Output maps.  t2/k/sigma/res are the reference's four maps (utils/t2map_utils.py:18-29); the
+ * others are optional (NULL = not wanted) and replace the per-voxel tuples fit_voxel returns
+ * (run_t2mapping.py:312).  All arrays have n_vox elements. */
+typedef struct t2fit_maps {
+  float *t2;       /* result.x[1]  (run_t2mapping.py:456-458)                                   */
+  float *k;        /* result.x[0]                                                               */
+  float *sigma;    /* result.x[2]; zeros for the 2-parameter model                              */
+  float *res;      /* mean signed residual over TE (utils/t2map_utils.py:84)                    */
+  float *r2;       /* optional: 1 - SS_res/SS_tot about the mean (no reference map; extension)  */
+  float *fun;      /* optional: final objective value (result.fun, :293)                        */
+  int32_t *nit;    /* optional: iterations (result.nit, :292)                                   */
+  uint8_t *status; /* optional: T2FIT_ST_*                                                      */
+} t2fit_maps;
+
+/* Fill *cfg with the reference table for (model, low_field): x0, bounds, ftol/gtol/maxls from
+ * run_t2mapping.py:38-106, scipy defaults for the rest, solver = L-BFGS-B.  Replaces
+ * set_fit_params() (run_t2mapping.py:29-111). */
+int t2fit_config_default(t2fit_config *cfg, int model, int low_field);
+
+/* Number of HIP devices visible (0 when there is none; never fails). */
+int t2fit_device_count(void);
+
+/* Volume seam, device buffers: replaces run_t2mapping.py:427-461 (Pool.map over fit_voxel, the
+ * scatter into maps and compute_residuals) for one (sub,ses).
+ *   echoes_dev : float32, layout per `layout`
+ *   mask_dev   : uint8 [n_vox] (non-zero = fit), or NULL to fit every voxel
+ *   maps       : device pointers
+ * Asynchronous on `stream`; the caller synchronises. */
+int t2fit_volume_dev(const t2fit_config *cfg, const float *echoes_dev, int layout,
+                     const uint8_t *mask_dev, int64_t n_vox, const t2fit_maps *maps, void *stream);
+
+/* Same seam with host buffers (numpy arrays): allocates device staging, copies in, fits, copies
+ * the requested maps out, synchronises.  `device` = HIP device ordinal. */
+int t2fit_volume_host(const t2fit_config *cfg, const float *echoes, int layout, const uint8_t *mask,
+                      int64_t n_vox, const t2fit_maps *maps, int device);
+
+/* Voxel seam (run_t2mapping.py:120 fit_voxel, batched): fit rows idx[0..n_idx) of the
+ * (N, nTE) or (nTE, N) stack and return the per-voxel tuple fields densely packed:
+ *   x[n_idx*3] float64 (k, T2, sigma; sigma = 0 for the 2-parameter model), fun[n_idx] float64,
+ *   nit[n_idx], status[n_idx].  Host pointers. */
+int t2fit_voxels_host(const t2fit_config *cfg, const float *echoes, int layout, int64_t n_vox,
+                      const int64_t *idx, int64_t n_idx, double *x, double *fun, int32_t *nit,
+                      uint8_t *status, int device);
+
+/* Union mask + flat indices: replaces run_t2mapping.py:383-384,412,421.
+ *   masks_dev : n_masks volumes of uint8 [n_vox] each, contiguous (n_masks, n_vox)
+ *   mask_out  : uint8 [n_vox], 1 where any input mask is non-zero
+ *   idx_out   : int64 [n_vox] capacity; ascending flat indices of the union (np.where order)
+ *   count_out : device int64, number of indices written
+ * Asynchronous on `stream`. */
+int t2fit_union_mask_dev(const uint8_t *masks_dev, int n_masks, int64_t n_vox, uint8_t *mask_out,
+                         int64_t *idx_out, int64_t *count_out, void *stream);
+
+/* Residual map alone: replaces compute_residuals (utils/t2map_utils.py:62-89) for maps that are
+ * already on the device (all float32 [n_vox]). */
+int t2fit_residuals_dev(const t2fit_config *cfg, const float *echoes_dev, int layout,
+                        const uint8_t *mask_dev, int64_t n_vox, const float *t2, const float *k,
+                        const float *sigma, float *res, void *stream);
+
+/* Duration in milliseconds of the last fit kernel launched by this thread's most recent
+ * t2fit_volume_dev call with timing enabled (t2fit_set_timing(1)); measured with HIP events on
+ * the launch stream.  Returns a negative value when unavailable. */
+int t2fit_set_timing(int enabled);
+double t2fit_last_kernel_ms(void);
+
+const char *t2fit_last_error(void);
+int t2fit_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T2FIT_H */

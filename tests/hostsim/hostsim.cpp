@@ -1,0 +1,35 @@
+// hostsim.cpp -- TEST INFRASTRUCTURE: compiles the per-lane solver headers for the host CPU so
+// that solver logic can be checked against the golden fixtures where no GPU exists.  It is built
+// by tests/hostsim/build.py into tests/hostsim/libt2fit_hostsim.so and loaded only by tests/;
+// the product package never loads it and has no CPU execution path.
+#include "../../fetal_t2mapping_amd/csrc/t2fit_config.h"
+#include "../../fetal_t2mapping_amd/csrc/t2fit_dispatch.h"
+
+using namespace t2fit;
+
+extern "C" int hostsim_config_default(t2fit_config* cfg, int model, int low_field) {
+  return config_default_impl(cfg, model, low_field);
+}
+
+// rows: (n, nTE) voxel-major float32
+extern "C" int hostsim_fit_rows(const t2fit_config* cfg, const float* rows, int64_t n, double* x,
+                                double* fun, int32_t* nit, uint8_t* status, float* res, float* r2) {
+  const char* why;
+  int rc = config_check(cfg, &why);
+  if (rc != T2FIT_OK) return rc;
+  const LaneParams P = make_lane_params(*cfg);
+  for (int64_t v = 0; v < n; ++v) {
+    EchoView y{rows + v * cfg->n_te, 1};
+    LaneResult r;
+    fit_lane(P, y, r);
+    LaneOutputs o;
+    lane_epilogue(P, y, r, o, r2 != nullptr);
+    for (int j = 0; j < 3; ++j) x[v * 3 + j] = r.x[j];
+    fun[v] = r.fun;
+    nit[v] = r.nit;
+    status[v] = r.status;
+    if (res) res[v] = o.res;
+    if (r2) r2[v] = o.r2;
+  }
+  return 0;
+}

@@ -1,0 +1,68 @@
+"""Loader for the host-side lane simulator (test infrastructure, see hostsim.cpp)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from fetal_t2mapping_amd import _abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libt2fit_hostsim.so")
+SRC = os.path.join(HERE, "hostsim.cpp")
+CSRC = os.path.join(os.path.dirname(os.path.dirname(HERE)), "fetal_t2mapping_amd", "csrc")
+
+
+def build(force: bool = False) -> str:
+    deps = [SRC] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps.append(os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "t2fit.h"))
+    if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in deps):
+        return SO
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-o", SO, SRC])
+    return SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.hostsim_config_default.argtypes = [C.POINTER(_abi.T2FitConfig), C.c_int, C.c_int]
+        _lib.hostsim_fit_rows.argtypes = [C.POINTER(_abi.T2FitConfig), C.c_void_p, C.c_int64] + [C.c_void_p] * 6
+    return _lib
+
+
+def config(mode: str, low_field: bool, te, prior=True, norm=False, solver="lbfgsb", precision="f64"):
+    cfg = _abi.T2FitConfig()
+    assert lib().hostsim_config_default(C.byref(cfg), _abi.MODELS[mode], int(low_field)) == 0
+    te = np.asarray(te, np.float64)
+    cfg.n_te = len(te)
+    for i, t in enumerate(te):
+        cfg.te_ms[i] = t
+    cfg.no_prior = int(not prior)
+    cfg.norm = int(norm)
+    cfg.solver = _abi.SOLVERS[solver]
+    cfg.precision = _abi.PRECISIONS[precision]
+    if solver == "lm":
+        cfg.maxiter = 0
+    return cfg
+
+
+def fit_rows(cfg, rows):
+    rows = np.ascontiguousarray(rows, np.float32)
+    n = rows.shape[0]
+    x = np.zeros((n, 3))
+    fun = np.zeros(n)
+    nit = np.zeros(n, np.int32)
+    st = np.zeros(n, np.uint8)
+    res = np.zeros(n, np.float32)
+    r2 = np.zeros(n, np.float32)
+    rc = lib().hostsim_fit_rows(C.byref(cfg), rows.ctypes.data, n, x.ctypes.data, fun.ctypes.data,
+                                nit.ctypes.data, st.ctypes.data, res.ctypes.data, r2.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"hostsim_fit_rows rc={rc}")
+    return {"x": x, "fun": fun, "nit": nit, "status": st, "res": res, "r2": r2}

@@ -1,0 +1,117 @@
+"""Pin the CPU oracle (oracle/t2fit_oracle.py) to the reference's own outputs.
+
+The fixtures under tests/golden/ were produced by importing the reference's ``fit_voxel``,
+``compute_residuals`` and ``process_t2maps`` (tests/golden/make_golden.py).  Because the oracle
+drives the same scipy entry point with the same arguments, agreement is required BIT-FOR-BIT when
+the interpreter's numpy/scipy match the versions recorded in the fixture.
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+import scipy
+
+from conftest import golden_voxel_files
+from oracle import t2fit_oracle as O
+
+FILES = golden_voxel_files()
+
+
+def _same_versions(d):
+    return str(d["numpy_version"]) == np.__version__ and str(d["scipy_version"]) == scipy.__version__
+
+
+def test_fixture_inventory():
+    # 2 fields x 3 modes x 2 prior settings x 3 echo counts
+    assert len(FILES) == 36
+    assert os.path.exists(os.path.join(os.path.dirname(FILES[0]), "volume_lf_gaussian_noprior.npz"))
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[7:-4] for f in FILES])
+def test_fit_voxel_matches_reference(path):
+    d = np.load(path)
+    mode, low_field, prior = str(d["mode"]), bool(d["low_field"]), bool(d["prior"])
+    table = O.fit_table(mode, low_field)
+    assert np.array_equal(np.array(table["initial_guess"], float), d["x0"])
+    assert np.array_equal(np.array(table["param_bounds"], float), d["table_bounds"])
+    y, te = d["y"], d["te"]
+    # every edge row + a spread of random rows keeps the CPU suite short
+    rows = list(range(int(d["trace_first_row"]) + 8)) + list(range(40, y.shape[0], 9))
+    fp = copy.deepcopy(table)
+    exact = _same_versions(d)
+    for v in rows:
+        with np.errstate(all="ignore"):
+            try:
+                x, ok, nit, f, info = O.fit_voxel(v, mode, fp, te, y, prior, False)
+            except ValueError:
+                assert d["raised"][v], f"row {v}: oracle raised, reference did not"
+                continue
+        assert not d["raised"][v]
+        if exact:
+            assert np.array_equal(x, d["x"][v], equal_nan=True), (v, x, d["x"][v])
+            assert nit == d["nit"][v] and ok == d["success"][v]
+            assert (f == d["fun"][v]) or (np.isnan(f) and np.isnan(d["fun"][v]))
+        else:  # other scipy build: same algorithm, different binary -> statistical agreement only
+            assert ok == d["success"][v]
+        t = v - int(d["trace_first_row"])
+        if exact and 0 <= t < d["trace_f"].shape[0]:
+            n = min(len(info), d["trace_f"].shape[1])
+            assert np.array_equal([e["f_val"] for e in info[:n]], d["trace_f"][t, :n])
+            assert np.array_equal([e["step_size"] for e in info[:n]], d["trace_step"][t, :n], equal_nan=True)
+
+
+@pytest.mark.parametrize("path", FILES[::5], ids=[os.path.basename(f)[7:-4] for f in FILES[::5]])
+def test_compute_residuals_matches_reference(path):
+    d = np.load(path)
+    mode = str(d["mode"])
+    y, te, x = d["y"], d["te"], d["x"]
+    m = y.shape[0]
+    rows = np.where(~d["raised"])[0]
+    k = np.zeros(m, np.float32)
+    t2 = np.zeros(m, np.float32)
+    sg = np.zeros(m, np.float32)
+    k[rows] = x[rows, 0].astype(np.float32)
+    t2[rows] = x[rows, 1].astype(np.float32)
+    if x.shape[1] == 3:
+        sg[rows] = x[rows, 2].astype(np.float32)
+    res = O.compute_residuals(y, te, mode, False, k, t2, sg, np.zeros(m, np.float32), rows)
+    if str(d["numpy_version"]) == np.__version__:
+        assert np.array_equal(res, d["res"], equal_nan=True)
+    else:
+        assert np.allclose(res, d["res"], rtol=0, atol=1e-3, equal_nan=True)
+
+
+def test_volume_path_matches_reference(golden_dir):
+    """Whole process_t2maps run of the reference vs the oracle's stack/flatten + fit + scatter."""
+    d = np.load(os.path.join(golden_dir, "volume_lf_gaussian_noprior.npz"))
+    echoes, masks, te = d["echoes"], d["masks"], d["te"]
+    data, mask, idx = O.stack_mask_flatten(list(echoes), list(masks))
+    assert data.dtype == np.float32 and data.shape == (echoes[0].size, len(te))
+    assert idx.dtype == np.int64 and np.all(np.diff(idx) > 0)
+    assert mask.sum() == len(idx) == int((masks.sum(axis=0) > 0).sum())
+    fit = O.fit_volume(data, idx, te, "gaussian", O.fit_table("gaussian", True), prior=False)
+    shape = echoes.shape[1:]
+    same = str(d["numpy_version"]) == np.__version__ and str(d["scipy_version"]) == scipy.__version__
+    for name, got in (("t2", fit.t2), ("k", fit.k), ("sigma", fit.sigma), ("res", fit.res)):
+        want = d[name]
+        got = got.reshape(shape)
+        if same:
+            assert np.array_equal(got, want), name
+        else:
+            assert np.allclose(got, want, rtol=1e-4, atol=1e-2), name
+    # zeros outside the mask (run_t2mapping.py:415-418)
+    assert np.all(fit.t2.reshape(shape)[~mask] == 0)
+    names = [str(s) for s in d["written"]]
+    assert names == sorted(
+        f"prj-900/derivatives/recon_1mm_t2map/sub-001/ses-01/anat/sub-001_ses-01_recon_1mm_sim-g1_{p}map_ada-gaussian.nii.gz"
+        for p in ("t2", "k", "sigma", "res"))
+
+
+def test_tight_solution_is_no_worse_than_reference():
+    """The second golden set (converged bounded minimiser) must never lose to the reference."""
+    for path in FILES:
+        d = np.load(path)
+        ok = np.isfinite(d["fun"]) & np.isfinite(d["f_tight"])
+        assert ok.sum() > 200
+        assert np.all(d["f_tight"][ok] <= d["fun"][ok] * (1 + 1e-9) + 1e-12), path
