@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mvoxel/s of the per-voxel T2 fit on synthetic 256^3 x 8 TE volumes.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one rank's slab: the fit kernel over 256^3 voxels x 8 echoes
+already resident in HBM (t2fit_volume_dev) and, for N > 1, the RCCL all-gather of the four output
+maps that BASELINE.json's north_star asks for.  Weak scaling: every rank fits its own 256^3 slab.
+`value` = voxels fitted by all ranks / wall time (max over ranks) in Mvoxel/s.
+
+The JSON line also carries
+  roofline     : achieved algorithmic HBM GB/s of the fit kernel (49 B/voxel at 8 TE: 4*nTE samples
+                 + 1 mask byte + 4 float32 maps) over its mean launch duration, measured
+                 with HIP events on the launch stream inside the library, against 8 TB/s.
+  cpu_baseline : the CPU oracle (oracle/t2fit_oracle.py: the reference's scipy L-BFGS-B loop restated)
+                 timed on this host's cores over a bounded sample of the same masked voxels.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--shape", type=int, nargs=3, default=[256, 256, 256], help="per-rank slab Z Y X")
+    p.add_argument("--n-te", type=int, default=8)
+    p.add_argument("--fit", default="gaussian_rician", choices=["gaussian", "gaussian_rician", "rician"])
+    p.add_argument("--solver", default="lbfgsb", choices=["lbfgsb", "lm"])
+    p.add_argument("--precision", default="f64", choices=["f64", "f32"])
+    p.add_argument("--no-prior", action="store_true")
+    p.add_argument("--no-gather", action="store_true", help="skip the all-gather of the maps (N > 1)")
+    p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration (0 = skip)")
+    return p.parse_args()
+
+
+def cpu_baseline(echoes_rows, te, fit, prior, seconds):
+    """Reference-equivalent scipy loop (the oracle) on all host cores over a bounded voxel sample."""
+    import multiprocessing as mp
+
+    import numpy as np
+
+    from oracle import t2fit_oracle as O
+
+    os.environ["OPENBLAS_NUM_THREADS"] = "1"
+    os.environ["OMP_NUM_THREADS"] = "1"
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    table = O.fit_table(fit, True)
+    # calibrate on a few voxels, then size the sample for ~`seconds` of wall time
+    t0 = time.perf_counter()
+    probe = min(40, echoes_rows.shape[0])
+    O.fit_volume(echoes_rows[:probe], np.arange(probe), te, fit, table, prior=prior)
+    per_voxel = (time.perf_counter() - t0) / probe
+    n = int(min(echoes_rows.shape[0], max(cores * 50, seconds * cores / per_voxel)))
+    rows = echoes_rows[:n]
+    with mp.get_context("fork").Pool(cores) as pool:
+        t0 = time.perf_counter()
+        O.fit_volume(rows, np.arange(n), te, fit, table, prior=prior, pool=pool)
+        dt = time.perf_counter() - t0
+    return {"value": n / dt / 1e6, "unit": "Mvoxel/s", "cores": cores, "kind": "port",
+            "sample": f"{n} masked voxels of a 6-slice slab of the same synthetic distribution, scipy {__import__('scipy').__version__} "
+                      f"L-BFGS-B loop (oracle/t2fit_oracle.py) on a {cores}-process pool, {dt:.1f} s"}
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import fetal_t2mapping_amd as t2
+    from fetal_t2mapping_amd import _abi, synth
+    from fetal_t2mapping_amd._lib import check, require_gpu
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        a.gpus = world
+    cpu = None
+    if world == 1 and a.cpu_seconds > 0:
+        # timed BEFORE this process touches the GPU (the worker pool forks); a thin slab of the
+        # same synthetic distribution: same TE vector, k/T2/noise ranges and mask shape
+        ev, mv, te_c = synth.brain_volume((6, a.shape[1], a.shape[2]), a.n_te, synth.SEED_BASE + 3)
+        rows = np.ascontiguousarray(ev.reshape(a.n_te, -1)[:, mv.reshape(-1) != 0].T)
+        cpu = cpu_baseline(rows, te_c, a.fit, not a.no_prior, a.cpu_seconds)
+    lib = require_gpu()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    z, y, x = a.shape
+    n_vox = z * y * x
+    echoes, mask, te = synth.brain_volume_torch((z, y, x), a.n_te, synth.SEED_BASE + 3 + rank, dev)
+    table = t2.fit_table(a.fit, True)
+    cfg = t2.make_config(a.fit, table, te, prior=not a.no_prior, norm=False, solver=a.solver, precision=a.precision)
+    # packed output slab [4, n_vox]: t2, k, sigma, res -- one all-gather moves all four maps
+    packed = torch.empty((4, n_vox), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world, 4, n_vox), dtype=torch.float32, device=dev) if world > 1 and not a.no_gather else None
+    maps = _abi.T2FitMaps()
+    maps.t2, maps.k, maps.sigma, maps.res = (packed[j].data_ptr() for j in range(4))
+    stream = torch.cuda.current_stream()
+    st = C.c_void_p(stream.cuda_stream)
+    lib.t2fit_set_timing(1)
+    kernel_ms = []
+
+    def step(record):
+        check(lib.t2fit_volume_dev(C.byref(cfg), echoes.data_ptr(), _abi.LAYOUT_TE_MAJOR, mask.data_ptr(), n_vox,
+                                   C.byref(maps), st))
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1))
+        if record:
+            kernel_ms.append(lib.t2fit_last_kernel_ms())  # syncs on the kernel's stop event only
+
+    for _ in range(a.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        value = world * n_vox / (elapsed / a.steps) / 1e6
+        bytes_per_voxel = 4 * a.n_te + 1 + 16
+        k_ms = float(np.mean(kernel_ms))
+        achieved = bytes_per_voxel * n_vox / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "traffic.json")
+        if os.path.exists(tpath):  # HBM bytes per launch from separate rocprofv3 --pmc passes (see profiles/README.md)
+            with open(tpath) as f:
+                t = json.load(f)
+            key = f"{a.fit}/{a.solver}/{a.precision}/{z}x{y}x{x}x{a.n_te}"
+            traffic = t.get(key)
+        masked = int(mask.sum().item())
+        out = {
+            "metric": "Mvoxel/s T2 fit, 256^3 x 8TE 3-param, whole job",
+            "value": round(value, 3), "unit": "Mvoxel/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64" if a.solver == "lbfgsb" else a.precision, "data": "synthetic",
+            "config": {"workload": f"{z}x{y}x{x} voxels x {a.n_te} TE per GPU, {a.fit} objective, "
+                                   f"{'reference-trajectory L-BFGS-B' if a.solver == 'lbfgsb' else 'bounded LM'} solver, "
+                                   f"{'prior' if not a.no_prior else 'no-prior'} bounds, mask fill {masked / n_vox:.2f}",
+                       "solver": a.solver, "fit": a.fit, "n_te": a.n_te, "voxels_per_gpu": n_vox,
+                       "masked_voxels_per_gpu": masked,
+                       "parallelism": f"voxel slabs x{world}" + (" + all-gather of 4 maps" if gathered is not None else "")},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "kernel": "fit_volume_kernel", "kernel_ms": round(k_ms, 4),
+                         "bytes_per_voxel": bytes_per_voxel},
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,5 +1,9 @@
 // t2fit_dispatch.h -- one voxel end to end: input checks, bounds, solver choice, epilogue values.
 // Mirrors the control flow of fit_voxel (run_t2mapping.py:237-312) for a single lane.
+//
+// fit_lane_t<SOLVER, PREC, MODEL> is the compile-time specialised lane body each kernel
+// instantiation uses (so its register allocation covers one path only); fit_lane() is the runtime
+// switch used by the host-side lane simulator in tests/.
 #pragma once
 
 #include "t2fit_lane.h"
@@ -30,15 +34,14 @@ struct LaneOutputs {
   uint8_t status;
 };
 
-T2_HD void fit_lane(const LaneParams& P, EchoView y, LaneResult& r) {
+T2_HD ObjCtx make_ctx(const LaneParams& P, EchoView y, bool& finite) {
   const int n = P.n_te;
-  const int np = n_params(P.model);
   ObjCtx c;
   c.P = &P;
   c.y = y;
   c.norm = P.norm != 0;
   c.ymax = 1.0f;
-  bool finite = true;
+  finite = true;
   float ymax = y[0];
   for (int i = 0; i < n; ++i) {
     const float v = y[i];
@@ -49,49 +52,62 @@ T2_HD void fit_lane(const LaneParams& P, EchoView y, LaneResult& r) {
     c.ymax = ymax;
     for (int i = 0; i < n; ++i) finite = finite && t2_finite(c.sample(i));
   }
+  return c;
+}
+
+template <int SOLVER, int PREC, int MODEL>
+T2_HD void fit_lane_t(const LaneParams& P, EchoView y, LaneResult& r) {
+  constexpr int NP = MODEL == T2FIT_MODEL_GAUSSIAN ? 2 : 3;
+  bool finite;
+  const ObjCtx c = make_ctx(P, y, finite);
   double lb[3], ub[3];
   const bool feasible = lane_bounds(P, y[0], lb, ub);
   r.nit = 0;
   r.fun = NAN;
   if (!feasible) {
     // scipy raises "one of the lower bounds is greater than an upper bound" (whole volume aborts)
-    r.x[0] = r.x[1] = r.x[2] = NAN;
-    if (np == 2) r.x[2] = 0.0;
+    r.x[0] = r.x[1] = NAN;
+    r.x[2] = NP == 2 ? 0.0 : NAN;
     r.status = T2FIT_ST_INFEASIBLE;
     return;
   }
   if (!finite) {
     // objective is NaN everywhere: scipy stops at the clipped start point, nit = 0, success False
-    for (int j = 0; j < 3; ++j) r.x[j] = j < np ? t2_clip(P.x0[j], lb[j], ub[j]) : 0.0;
+    for (int j = 0; j < 3; ++j) r.x[j] = j < NP ? t2_clip(P.x0[j], lb[j], ub[j]) : 0.0;
     r.status = T2FIT_ST_NONFINITE;
     return;
   }
+  if constexpr (SOLVER == T2FIT_SOLVER_LM) {
+    static_assert(MODEL != T2FIT_MODEL_RICIAN, "LM handles the least-squares models only");
+    if constexpr (PREC == T2FIT_PREC_F32) lm_solve<float, NP>(c, lb, ub, r);
+    else lm_solve<double, NP>(c, lb, ub, r);
+  } else {
+    lbfgsb_solve<MODEL>(c, lb, ub, r);
+  }
+}
+
+// runtime switch (host simulator); the kernels pick the instantiation at launch time instead
+T2_HD void fit_lane(const LaneParams& P, EchoView y, LaneResult& r) {
   if (P.solver == T2FIT_SOLVER_LM) {
     if (P.precision == T2FIT_PREC_F32) {
-      if (np == 2) lm_solve<float, 2>(c, lb, ub, r);
-      else lm_solve<float, 3>(c, lb, ub, r);
+      if (P.model == T2FIT_MODEL_GAUSSIAN) fit_lane_t<T2FIT_SOLVER_LM, T2FIT_PREC_F32, T2FIT_MODEL_GAUSSIAN>(P, y, r);
+      else fit_lane_t<T2FIT_SOLVER_LM, T2FIT_PREC_F32, T2FIT_MODEL_GAUSSIAN_RICIAN>(P, y, r);
     } else {
-      if (np == 2) lm_solve<double, 2>(c, lb, ub, r);
-      else lm_solve<double, 3>(c, lb, ub, r);
+      if (P.model == T2FIT_MODEL_GAUSSIAN) fit_lane_t<T2FIT_SOLVER_LM, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN>(P, y, r);
+      else fit_lane_t<T2FIT_SOLVER_LM, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN_RICIAN>(P, y, r);
     }
   } else {
-    lbfgsb_solve(c, lb, ub, r);
+    if (P.model == T2FIT_MODEL_GAUSSIAN) fit_lane_t<T2FIT_SOLVER_LBFGSB, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN>(P, y, r);
+    else if (P.model == T2FIT_MODEL_GAUSSIAN_RICIAN) fit_lane_t<T2FIT_SOLVER_LBFGSB, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN_RICIAN>(P, y, r);
+    else fit_lane_t<T2FIT_SOLVER_LBFGSB, T2FIT_PREC_F64, T2FIT_MODEL_RICIAN>(P, y, r);
   }
 }
 
 // Epilogue: float32 map values, residual map and optional R^2 from the float32 parameters
 // (run_t2mapping.py:456-458 casts, utils/t2map_utils.py:62-89).
 T2_HD void lane_epilogue(const LaneParams& P, EchoView y, const LaneResult& r, LaneOutputs& o, bool want_r2) {
-  ObjCtx c;
-  c.P = &P;
-  c.y = y;
-  c.norm = P.norm != 0;
-  c.ymax = 1.0f;
-  if (c.norm) {
-    float ymax = y[0];
-    for (int i = 1; i < P.n_te; ++i) ymax = y[i] > ymax ? y[i] : ymax;
-    c.ymax = ymax;
-  }
+  bool finite;
+  const ObjCtx c = make_ctx(P, y, finite);
   o.k = (float)r.x[0];
   o.t2 = (float)r.x[1];
   o.sigma = (float)r.x[2];
@@ -108,12 +124,11 @@ T2_HD void lane_epilogue(const LaneParams& P, EchoView y, const LaneResult& r, L
     for (int i = 0; i < n; ++i) mean += (double)c.sample(i);
     mean /= n;
     double ss_tot = 0.0, ss_res = 0.0;
-    const bool gauss = P.model == T2FIT_MODEL_GAUSSIAN;
+    const bool sq = P.model == T2FIT_MODEL_GAUSSIAN_RICIAN;
     for (int i = 0; i < n; ++i) {
       const double yi = (double)c.sample(i);
       const double E = t2_exp(-P.te[i] / r.x[1]);
-      const double m = gauss || P.model == T2FIT_MODEL_RICIAN ? r.x[0] * E
-                                                                : t2_sqrt(r.x[0] * r.x[0] * E * E + r.x[2] * r.x[2]);
+      const double m = sq ? t2_sqrt(r.x[0] * r.x[0] * E * E + r.x[2] * r.x[2]) : r.x[0] * E;
       ss_res += (yi - m) * (yi - m);
       ss_tot += (yi - mean) * (yi - mean);
     }

@@ -1,0 +1,464 @@
+// t2fit_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the per-voxel T2 fit and the C ABI of
+// include/t2fit.h.  Built with:  hipcc -O3 --offload-arch=gfx950 -shared -fPIC
+//
+// Mapping: one lane per voxel, 256-thread workgroups (4 wave64), grid = ceil(N / 256) >> 256 CUs.
+// HBM layout: echoes (nTE, N) float32 -- lane v of a wave reads echoes[i*N + base + v], so every TE
+// plane read is one fully coalesced 256-byte wave access; each sample is read exactly once and
+// parked in LDS ([nTE][257] floats per workgroup, one column per lane, padded so the
+// voxel-major staging transpose is conflict-free).  The solver then re-reads its column from LDS
+// on every objective evaluation instead of holding nTE samples in VGPRs (nTE is a run-time value).
+// Each map is written once, one dword per lane, coalesced.  Algorithmic HBM traffic per voxel:
+// 4*nTE (samples) + 1 (mask) + 16 (t2,k,sigma,res)  =  49 B at 8 TE.
+// The fit itself is ALU work (exp/sqrt/fma, fp32 or fp64); no MFMA: nothing here is a contraction.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "t2fit_config.h"
+#include "t2fit_dispatch.h"
+
+using namespace t2fit;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kLdsStride = kBlock + 1;
+
+thread_local std::string g_err;
+thread_local bool g_timing = false;
+thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+thread_local bool g_ev_valid = false;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define T2_HIP(call)                                                                            \
+  do {                                                                                          \
+    hipError_t e_ = (call);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return fail(T2FIT_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));             \
+  } while (0)
+
+struct DevMaps {
+  float *t2, *k, *sigma, *res, *r2, *fun;
+  int32_t* nit;
+  uint8_t* status;
+  double* xd;    // optional: float64 parameters, 3 per voxel (voxel seam)
+  double* fund;  // optional: float64 objective value
+};
+
+// Stage this workgroup's samples into LDS.  TE-major: each lane copies its own column (coalesced
+// per plane, no exchange needed).  Voxel-major: the (256, nTE) tile is contiguous in HBM, so it is
+// read linearly by the whole workgroup and transposed on the way into LDS.
+__device__ __forceinline__ void stage_echoes(float* lds, const float* __restrict__ echoes, int layout,
+                                             int n_te, int64_t n_vox, int64_t base, bool load_own) {
+  const int lane = threadIdx.x;
+  if (layout == T2FIT_LAYOUT_TE_MAJOR) {
+    if (load_own) {
+      const float* src = echoes + base + lane;
+      for (int i = 0; i < n_te; ++i) lds[i * kLdsStride + lane] = src[(int64_t)i * n_vox];
+    }
+  } else {
+    const int64_t rows = n_vox - base < kBlock ? n_vox - base : kBlock;
+    const int total = (int)rows * n_te;
+    const float* src = echoes + base * n_te;
+    for (int j = lane; j < total; j += kBlock) {
+      const int v = j / n_te;
+      const int i = j - v * n_te;
+      lds[i * kLdsStride + v] = src[j];
+    }
+    __syncthreads();
+  }
+}
+
+template <int SOLVER, int PREC, int MODEL>
+__global__ __launch_bounds__(kBlock) void fit_volume_kernel(const LaneParams P, const float* __restrict__ echoes,
+                                                            int layout, const uint8_t* __restrict__ mask,
+                                                            int64_t n_vox, DevMaps m) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * kBlock;
+  const int64_t v = base + lane;
+  const bool in_range = v < n_vox;
+  const bool active = in_range && (mask == nullptr || mask[v] != 0);
+  stage_echoes(lds, echoes, layout, P.n_te, n_vox, base, active);
+  if (!in_range) return;
+  if (!active) {  // zeros outside the mask (run_t2mapping.py:415-418)
+    m.t2[v] = 0.0f; m.k[v] = 0.0f; m.sigma[v] = 0.0f; m.res[v] = 0.0f;
+    if (m.r2) m.r2[v] = 0.0f;
+    if (m.fun) m.fun[v] = 0.0f;
+    if (m.nit) m.nit[v] = 0;
+    if (m.status) m.status[v] = T2FIT_ST_MASKED;
+    if (m.xd) { m.xd[3 * v] = 0.0; m.xd[3 * v + 1] = 0.0; m.xd[3 * v + 2] = 0.0; }
+    if (m.fund) m.fund[v] = 0.0;
+    return;
+  }
+  const EchoView y{lds + lane, kLdsStride};
+  LaneResult r;
+  fit_lane_t<SOLVER, PREC, MODEL>(P, y, r);
+  LaneOutputs o;
+  lane_epilogue(P, y, r, o, m.r2 != nullptr);
+  m.t2[v] = o.t2; m.k[v] = o.k; m.sigma[v] = o.sigma; m.res[v] = o.res;
+  if (m.r2) m.r2[v] = o.r2;
+  if (m.fun) m.fun[v] = o.fun;
+  if (m.nit) m.nit[v] = o.nit;
+  if (m.status) m.status[v] = o.status;
+  if (m.xd) { m.xd[3 * v] = r.x[0]; m.xd[3 * v + 1] = r.x[1]; m.xd[3 * v + 2] = r.x[2]; }
+  if (m.fund) m.fund[v] = r.fun;
+}
+
+// Residual map only (utils/t2map_utils.py:62-89) from float32 maps already on the device.
+__global__ __launch_bounds__(kBlock) void residuals_kernel(const LaneParams P, const float* __restrict__ echoes,
+                                                           int layout, const uint8_t* __restrict__ mask,
+                                                           int64_t n_vox, const float* __restrict__ t2,
+                                                           const float* __restrict__ k,
+                                                           const float* __restrict__ sigma, float* res) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * kBlock;
+  const int64_t v = base + lane;
+  const bool in_range = v < n_vox;
+  const bool active = in_range && (mask == nullptr || mask[v] != 0);
+  stage_echoes(lds, echoes, layout, P.n_te, n_vox, base, active);
+  if (!in_range) return;
+  float out = 0.0f;
+  if (active) {
+    const EchoView y{lds + lane, kLdsStride};
+    bool finite;
+    const ObjCtx c = make_ctx(P, y, finite);
+    out = residual_mean(c, k[v], t2[v], sigma ? sigma[v] : 0.0f);
+  }
+  res[v] = out;
+}
+
+// ---- union mask + ordered flat indices (run_t2mapping.py:383-384,412,421) ----------------------
+constexpr int kScanItems = 4;                      // voxels per lane
+constexpr int kScanTile = kBlock * kScanItems;     // voxels per workgroup
+
+__device__ __forceinline__ uint8_t union_at(const uint8_t* __restrict__ masks, int n_masks, int64_t n_vox, int64_t v) {
+  uint8_t any = 0;
+  for (int j = 0; j < n_masks; ++j) any |= masks[(int64_t)j * n_vox + v] != 0;
+  return any;
+}
+
+__global__ __launch_bounds__(kBlock) void mask_count_kernel(const uint8_t* __restrict__ masks, int n_masks,
+                                                            int64_t n_vox, uint8_t* __restrict__ mask_out,
+                                                            int64_t* __restrict__ tile_counts) {
+  __shared__ int wave_sum[kBlock / 64];
+  const int64_t v0 = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  int cnt = 0;
+  for (int q = 0; q < kScanItems; ++q) {
+    const int64_t v = v0 + q;
+    if (v < n_vox) {
+      const uint8_t u = union_at(masks, n_masks, n_vox, v);
+      mask_out[v] = u;
+      cnt += u;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+  if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int w = 0; w < kBlock / 64; ++w) s += wave_sum[w];
+    tile_counts[blockIdx.x] = s;
+  }
+}
+
+// exclusive scan of the per-tile counts by one workgroup (tiles <= N/1024: tens of thousands)
+__global__ __launch_bounds__(1024) void tile_scan_kernel(int64_t* tile_counts, int64_t n_tiles, int64_t* total_out) {
+  __shared__ int64_t part[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (n_tiles + 1023) / 1024;
+  const int64_t lo = (int64_t)t * per;
+  const int64_t hi = lo + per < n_tiles ? lo + per : n_tiles;
+  int64_t s = 0;
+  for (int64_t i = lo; i < hi; ++i) s += tile_counts[i];
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    int64_t add = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += add;
+    __syncthreads();
+  }
+  int64_t run = t == 0 ? 0 : part[t - 1];
+  for (int64_t i = lo; i < hi; ++i) {
+    const int64_t c = tile_counts[i];
+    tile_counts[i] = run;
+    run += c;
+  }
+  if (t == 1023) *total_out = part[1023];
+}
+
+__global__ __launch_bounds__(kBlock) void mask_write_kernel(const uint8_t* __restrict__ mask, int64_t n_vox,
+                                                            const int64_t* __restrict__ tile_offsets,
+                                                            int64_t* __restrict__ idx_out) {
+  __shared__ int wave_sum[kBlock / 64];
+  const int64_t v0 = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  uint8_t f[kScanItems];
+  int cnt = 0;
+  for (int q = 0; q < kScanItems; ++q) {
+    const int64_t v = v0 + q;
+    f[q] = v < n_vox ? mask[v] : 0;
+    cnt += f[q];
+  }
+  // exclusive prefix of cnt within the wave, then across the 4 waves
+  int incl = cnt;
+  const int l = threadIdx.x & 63;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int up = __shfl_up(incl, off, 64);
+    if (l >= off) incl += up;
+  }
+  if (l == 63) wave_sum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  int wave_off = 0;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wave_off += wave_sum[w];
+  int64_t pos = tile_offsets[blockIdx.x] + wave_off + (incl - cnt);
+  for (int q = 0; q < kScanItems; ++q)
+    if (f[q]) idx_out[pos++] = v0 + q;
+}
+
+// ---- launch helpers -----------------------------------------------------------------------------
+using FitKernel = void (*)(const LaneParams, const float*, int, const uint8_t*, int64_t, DevMaps);
+
+FitKernel pick_kernel(const t2fit_config& c) {
+  if (c.solver == T2FIT_SOLVER_LM) {
+    if (c.precision == T2FIT_PREC_F32)
+      return c.model == T2FIT_MODEL_GAUSSIAN
+                 ? fit_volume_kernel<T2FIT_SOLVER_LM, T2FIT_PREC_F32, T2FIT_MODEL_GAUSSIAN>
+                 : fit_volume_kernel<T2FIT_SOLVER_LM, T2FIT_PREC_F32, T2FIT_MODEL_GAUSSIAN_RICIAN>;
+    return c.model == T2FIT_MODEL_GAUSSIAN
+               ? fit_volume_kernel<T2FIT_SOLVER_LM, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN>
+               : fit_volume_kernel<T2FIT_SOLVER_LM, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN_RICIAN>;
+  }
+  switch (c.model) {
+    case T2FIT_MODEL_GAUSSIAN: return fit_volume_kernel<T2FIT_SOLVER_LBFGSB, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN>;
+    case T2FIT_MODEL_GAUSSIAN_RICIAN:
+      return fit_volume_kernel<T2FIT_SOLVER_LBFGSB, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN_RICIAN>;
+    default: return fit_volume_kernel<T2FIT_SOLVER_LBFGSB, T2FIT_PREC_F64, T2FIT_MODEL_RICIAN>;
+  }
+}
+
+int check_common(const t2fit_config* cfg, const void* echoes, int layout, int64_t n_vox) {
+  const char* why;
+  const int rc = config_check(cfg, &why);
+  if (rc != T2FIT_OK) return fail(rc, why);
+  if (!echoes) return fail(T2FIT_E_INVALID, "echoes is NULL");
+  if (layout != T2FIT_LAYOUT_TE_MAJOR && layout != T2FIT_LAYOUT_VOXEL_MAJOR) return fail(T2FIT_E_INVALID, "unknown layout");
+  if (n_vox < 0) return fail(T2FIT_E_INVALID, "n_vox is negative");
+  if ((n_vox + kBlock - 1) / kBlock > 0x7fffffffLL) return fail(T2FIT_E_INVALID, "n_vox too large for one launch");
+  return T2FIT_OK;
+}
+
+int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const uint8_t* mask, int64_t n_vox,
+               const DevMaps& dm, hipStream_t st) {
+  if (n_vox == 0) return T2FIT_OK;
+  const LaneParams P = make_lane_params(*cfg);
+  const unsigned grid = (unsigned)((n_vox + kBlock - 1) / kBlock);
+  const size_t lds = (size_t)cfg->n_te * kLdsStride * sizeof(float);
+  FitKernel kern = pick_kernel(*cfg);
+  if (g_timing) {
+    if (!g_ev0) {
+      T2_HIP(hipEventCreate(&g_ev0));
+      T2_HIP(hipEventCreate(&g_ev1));
+    }
+    T2_HIP(hipEventRecord(g_ev0, st));
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox, dm);
+  T2_HIP(hipGetLastError());
+  if (g_timing) {
+    T2_HIP(hipEventRecord(g_ev1, st));
+    g_ev_valid = true;
+  }
+  return T2FIT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int t2fit_abi_version(void) { return T2FIT_ABI_VERSION; }
+
+const char* t2fit_last_error(void) { return g_err.c_str(); }
+
+int t2fit_config_default(t2fit_config* cfg, int model, int low_field) {
+  const int rc = config_default_impl(cfg, model, low_field);
+  return rc == T2FIT_OK ? rc : fail(rc, "t2fit_config_default: cfg is NULL or model unknown");
+}
+
+int t2fit_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int t2fit_set_timing(int enabled) {
+  g_timing = enabled != 0;
+  g_ev_valid = false;
+  return T2FIT_OK;
+}
+
+double t2fit_last_kernel_ms(void) {
+  if (!g_ev_valid) return -1.0;
+  if (hipEventSynchronize(g_ev1) != hipSuccess) return -1.0;
+  float ms = 0.0f;
+  if (hipEventElapsedTime(&ms, g_ev0, g_ev1) != hipSuccess) return -1.0;
+  return (double)ms;
+}
+
+int t2fit_volume_dev(const t2fit_config* cfg, const float* echoes_dev, int layout, const uint8_t* mask_dev,
+                     int64_t n_vox, const t2fit_maps* maps, void* stream) {
+  int rc = check_common(cfg, echoes_dev, layout, n_vox);
+  if (rc != T2FIT_OK) return rc;
+  if (!maps || !maps->t2 || !maps->k || !maps->sigma || !maps->res)
+    return fail(T2FIT_E_INVALID, "maps->t2/k/sigma/res must be non-NULL");
+  DevMaps dm{maps->t2, maps->k, maps->sigma, maps->res, maps->r2, maps->fun, maps->nit, maps->status, nullptr, nullptr};
+  return launch_fit(cfg, echoes_dev, layout, mask_dev, n_vox, dm, (hipStream_t)stream);
+}
+
+int t2fit_volume_host(const t2fit_config* cfg, const float* echoes, int layout, const uint8_t* mask, int64_t n_vox,
+                      const t2fit_maps* maps, int device) {
+  int rc = check_common(cfg, echoes, layout, n_vox);
+  if (rc != T2FIT_OK) return rc;
+  if (!maps || !maps->t2 || !maps->k || !maps->sigma || !maps->res)
+    return fail(T2FIT_E_INVALID, "maps->t2/k/sigma/res must be non-NULL");
+  if (n_vox == 0) return T2FIT_OK;
+  T2_HIP(hipSetDevice(device));
+  hipStream_t st;
+  T2_HIP(hipStreamCreate(&st));
+  const size_t nb_e = (size_t)n_vox * cfg->n_te * sizeof(float);
+  // one allocation: echoes | 6 float maps | nit | mask | status
+  const size_t off_maps = (nb_e + 255) & ~(size_t)255;
+  const size_t map_b = (((size_t)n_vox * 4) + 255) & ~(size_t)255;
+  const size_t off_nit = off_maps + 6 * map_b;
+  const size_t off_mask = off_nit + map_b;
+  const size_t byte_b = ((size_t)n_vox + 255) & ~(size_t)255;
+  const size_t off_status = off_mask + byte_b;
+  const size_t total = off_status + byte_b;
+  char* buf = nullptr;
+  hipError_t e = hipMalloc((void**)&buf, total);
+  if (e != hipSuccess) {
+    (void)hipStreamDestroy(st);
+    return fail(T2FIT_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+  }
+  auto cleanup = [&]() { (void)hipFree(buf); (void)hipStreamDestroy(st); };
+#define T2_HIP_C(call)                                                          \
+  do {                                                                          \
+    hipError_t e_ = (call);                                                     \
+    if (e_ != hipSuccess) {                                                     \
+      cleanup();                                                                \
+      return fail(T2FIT_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    }                                                                           \
+  } while (0)
+  T2_HIP_C(hipMemcpyAsync(buf, echoes, nb_e, hipMemcpyHostToDevice, st));
+  uint8_t* dmask = nullptr;
+  if (mask) {
+    dmask = (uint8_t*)(buf + off_mask);
+    T2_HIP_C(hipMemcpyAsync(dmask, mask, (size_t)n_vox, hipMemcpyHostToDevice, st));
+  }
+  float* fm[6];
+  for (int j = 0; j < 6; ++j) fm[j] = (float*)(buf + off_maps + j * map_b);
+  DevMaps dm{fm[0], fm[1], fm[2], fm[3], maps->r2 ? fm[4] : nullptr, maps->fun ? fm[5] : nullptr,
+             maps->nit ? (int32_t*)(buf + off_nit) : nullptr, maps->status ? (uint8_t*)(buf + off_status) : nullptr,
+             nullptr, nullptr};
+  rc = launch_fit(cfg, (const float*)buf, layout, dmask, n_vox, dm, st);
+  if (rc != T2FIT_OK) { cleanup(); return rc; }
+  float* host_f[6] = {maps->t2, maps->k, maps->sigma, maps->res, maps->r2, maps->fun};
+  for (int j = 0; j < 6; ++j)
+    if (host_f[j]) T2_HIP_C(hipMemcpyAsync(host_f[j], fm[j], (size_t)n_vox * 4, hipMemcpyDeviceToHost, st));
+  if (maps->nit) T2_HIP_C(hipMemcpyAsync(maps->nit, buf + off_nit, (size_t)n_vox * 4, hipMemcpyDeviceToHost, st));
+  if (maps->status) T2_HIP_C(hipMemcpyAsync(maps->status, buf + off_status, (size_t)n_vox, hipMemcpyDeviceToHost, st));
+  T2_HIP_C(hipStreamSynchronize(st));
+  cleanup();
+  return T2FIT_OK;
+}
+
+int t2fit_voxels_host(const t2fit_config* cfg, const float* echoes, int layout, int64_t n_vox, const int64_t* idx,
+                      int64_t n_idx, double* x, double* fun, int32_t* nit, uint8_t* status, int device) {
+  int rc = check_common(cfg, echoes, layout, n_vox);
+  if (rc != T2FIT_OK) return rc;
+  if (n_idx < 0 || (n_idx > 0 && (!idx || !x))) return fail(T2FIT_E_INVALID, "idx/x must be non-NULL");
+  if (n_idx == 0) return T2FIT_OK;
+  const int n_te = cfg->n_te;
+  // gather the requested rows into a compact voxel-major block on the host
+  std::vector<float> rows((size_t)n_idx * n_te);
+  for (int64_t r = 0; r < n_idx; ++r) {
+    const int64_t v = idx[r];
+    if (v < 0 || v >= n_vox) return fail(T2FIT_E_INVALID, "voxel index out of range");
+    for (int i = 0; i < n_te; ++i)
+      rows[(size_t)r * n_te + i] =
+          layout == T2FIT_LAYOUT_TE_MAJOR ? echoes[(size_t)i * n_vox + v] : echoes[(size_t)v * n_te + i];
+  }
+  T2_HIP(hipSetDevice(device));
+  const size_t nb_e = rows.size() * sizeof(float);
+  const size_t off_x = (nb_e + 255) & ~(size_t)255;
+  const size_t off_f = off_x + (((size_t)n_idx * 24 + 255) & ~(size_t)255);
+  const size_t off_maps = off_f + (((size_t)n_idx * 8 + 255) & ~(size_t)255);
+  const size_t map_b = (((size_t)n_idx * 4) + 255) & ~(size_t)255;
+  const size_t off_nit = off_maps + 4 * map_b;
+  const size_t off_status = off_nit + map_b;
+  const size_t total = off_status + (((size_t)n_idx + 255) & ~(size_t)255);
+  char* buf = nullptr;
+  T2_HIP(hipMalloc((void**)&buf, total));
+  auto cleanup = [&]() { (void)hipFree(buf); };
+  T2_HIP_C(hipMemcpy(buf, rows.data(), nb_e, hipMemcpyHostToDevice));
+  DevMaps dm{(float*)(buf + off_maps), (float*)(buf + off_maps + map_b), (float*)(buf + off_maps + 2 * map_b),
+             (float*)(buf + off_maps + 3 * map_b), nullptr, nullptr, (int32_t*)(buf + off_nit),
+             (uint8_t*)(buf + off_status), (double*)(buf + off_x), (double*)(buf + off_f)};
+  rc = launch_fit(cfg, (const float*)buf, T2FIT_LAYOUT_VOXEL_MAJOR, nullptr, n_idx, dm, nullptr);
+  if (rc != T2FIT_OK) { cleanup(); return rc; }
+  T2_HIP_C(hipDeviceSynchronize());
+  T2_HIP_C(hipMemcpy(x, buf + off_x, (size_t)n_idx * 24, hipMemcpyDeviceToHost));
+  if (fun) T2_HIP_C(hipMemcpy(fun, buf + off_f, (size_t)n_idx * 8, hipMemcpyDeviceToHost));
+  if (nit) T2_HIP_C(hipMemcpy(nit, buf + off_nit, (size_t)n_idx * 4, hipMemcpyDeviceToHost));
+  if (status) T2_HIP_C(hipMemcpy(status, buf + off_status, (size_t)n_idx, hipMemcpyDeviceToHost));
+  cleanup();
+  return T2FIT_OK;
+}
+
+int t2fit_union_mask_dev(const uint8_t* masks_dev, int n_masks, int64_t n_vox, uint8_t* mask_out, int64_t* idx_out,
+                         int64_t* count_out, void* stream) {
+  if (!masks_dev || !mask_out || !idx_out || !count_out) return fail(T2FIT_E_INVALID, "NULL pointer");
+  if (n_masks < 1 || n_vox < 0) return fail(T2FIT_E_INVALID, "n_masks < 1 or n_vox < 0");
+  hipStream_t st = (hipStream_t)stream;
+  if (n_vox == 0) {
+    T2_HIP(hipMemsetAsync(count_out, 0, sizeof(int64_t), st));
+    return T2FIT_OK;
+  }
+  const int64_t n_tiles = (n_vox + kScanTile - 1) / kScanTile;
+  if (n_tiles > 0x7fffffffLL) return fail(T2FIT_E_INVALID, "n_vox too large");
+  int64_t* tiles = nullptr;
+  T2_HIP(hipMallocAsync((void**)&tiles, (size_t)n_tiles * sizeof(int64_t), st));
+  hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, st, masks_dev, n_masks, n_vox, mask_out, tiles);
+  hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tiles, n_tiles, count_out);
+  hipLaunchKernelGGL(mask_write_kernel, dim3((unsigned)n_tiles), dim3(kBlock), 0, st, (const uint8_t*)mask_out, n_vox,
+                     (const int64_t*)tiles, idx_out);
+  T2_HIP(hipGetLastError());
+  T2_HIP(hipFreeAsync(tiles, st));
+  return T2FIT_OK;
+}
+
+int t2fit_residuals_dev(const t2fit_config* cfg, const float* echoes_dev, int layout, const uint8_t* mask_dev,
+                        int64_t n_vox, const float* t2, const float* k, const float* sigma, float* res, void* stream) {
+  int rc = check_common(cfg, echoes_dev, layout, n_vox);
+  if (rc != T2FIT_OK) return rc;
+  if (!t2 || !k || !res) return fail(T2FIT_E_INVALID, "t2/k/res must be non-NULL");
+  if (n_vox == 0) return T2FIT_OK;
+  const LaneParams P = make_lane_params(*cfg);
+  const unsigned grid = (unsigned)((n_vox + kBlock - 1) / kBlock);
+  const size_t lds = (size_t)cfg->n_te * kLdsStride * sizeof(float);
+  hipLaunchKernelGGL(residuals_kernel, dim3(grid), dim3(kBlock), lds, (hipStream_t)stream, P, echoes_dev, layout,
+                     mask_dev, n_vox, t2, k, sigma, res);
+  T2_HIP(hipGetLastError());
+  return T2FIT_OK;
+}
+
+}  // extern "C"

@@ -5,6 +5,7 @@
 
 namespace t2fit {
 
+template <int MODEL>
 T2_HD void lbfgsb_solve(const ObjCtx& c, const double* lb, const double* ub, LaneResult& out) {
   const int np = n_params(c.P->model);
   for (int j = 0; j < 3; ++j) out.x[j] = j < np ? t2_clip(c.P->x0[j], lb[j], ub[j]) : 0.0;

@@ -83,29 +83,36 @@ def brain_volume(shape, n_te: int, seed: int, low_field: bool = True, sigma: flo
     return echoes, mask.astype(np.uint8), te
 
 
-def brain_volume_torch(n_vox: int, n_te: int, seed: int, device, sigma: float = 20.0,
-                       fill: float = 0.45):
-    """Bench-size generator on the device (256^3 x 8 TE does not fit a quick numpy pass).
+def brain_volume_torch(shape, n_te: int, seed: int, device, sigma: float = 20.0, fill: float = 0.45,
+                       z_offset: int = 0, z_total: int | None = None):
+    """Bench-size generator on the device (256^3 x 8 TE is too slow as a numpy pass).
 
-    Same distribution as ``brain_volume`` but the mask is a seeded Bernoulli(fill) field: the
-    fit is per voxel, so spatial structure does not change the work.  Returns
-    ``(echoes (nTE, n_vox) f32, mask (n_vox,) u8, te f64 ndarray)`` as torch tensors on `device`.
+    Same distribution as ``brain_volume``: ellipsoidal mask filling ``fill`` of the (z_total, Y, X)
+    box, CSF pocket in the centre, Rician noise.  ``z_offset``/``z_total`` let one rank generate
+    its Z-slab of a taller volume.  Returns ``(echoes (nTE, Z*Y*X) f32, mask (Z*Y*X,) u8, te f64
+    ndarray)`` with the tensors on `device`.
     """
     import torch
 
+    z, y, x = shape
+    z_total = z if z_total is None else z_total
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     te = te_vector(n_te, True)
-    te_d = torch.tensor(te, dtype=torch.float32, device=device)
-    mask = torch.rand(n_vox, generator=g, device=device) < fill
+    n_vox = z * y * x
+    a = (fill * 6.0 / np.pi) ** (1.0 / 3.0)
+    lin = lambda n, off, tot: ((torch.arange(n, device=device, dtype=torch.float32) + off) * (2.0 / max(tot - 1, 1)) - 1.0) / a  # noqa: E731
+    r2 = (lin(z, z_offset, z_total)[:, None, None] ** 2 + lin(y, 0, y)[None, :, None] ** 2
+          + lin(x, 0, x)[None, None, :] ** 2).reshape(-1)
+    mask = r2 <= 1.0
+    csf = r2 <= 0.05
     k = torch.empty(n_vox, device=device).uniform_(700.0, 3000.0, generator=g)
     t2 = torch.empty(n_vox, device=device).uniform_(40.0, 400.0, generator=g)
-    csf = torch.rand(n_vox, generator=g, device=device) < 0.02
     t2 = torch.where(csf, torch.empty(n_vox, device=device).uniform_(600.0, 2000.0, generator=g), t2)
     k = torch.where(mask, k, torch.zeros_like(k))
     echoes = torch.empty((n_te, n_vox), dtype=torch.float32, device=device)
     for i in range(n_te):
-        clean = k * torch.exp(-te_d[i] / t2)
+        clean = k * torch.exp(-float(te[i]) / t2)
         n1 = torch.randn(n_vox, generator=g, device=device) * sigma
         n2 = torch.randn(n_vox, generator=g, device=device) * sigma
         echoes[i] = torch.hypot(clean + n1, n2)

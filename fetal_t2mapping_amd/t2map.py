@@ -1,0 +1,329 @@
+"""Host-side mirror of the reference's fitting interface, backed by the HIP library.
+
+Same names, argument meaning and error behaviour as the reference's hot path:
+
+=============================  ================================================================
+this module                    reference (paths relative to /root/reference)
+=============================  ================================================================
+``set_fit_params(args)``       run_t2mapping.py:29-111
+``fit_voxel(...)``             run_t2mapping.py:120-312 (one voxel; same 5-tuple)
+``fit_voxels(...)``            the ``Pool.map`` over ``fit_voxel`` (:430-443), batched
+``stack_mask_flatten(...)``    run_t2mapping.py:383-386,411-421
+``fit_volume(...)``            run_t2mapping.py:411-461 (flatten, fit, scatter, residual map)
+``compute_residuals(...)``     utils/t2map_utils.py:62-89
+=============================  ================================================================
+
+Python here only marshals buffers; all arithmetic happens in libt2fit_hip.so through the C ABI of
+include/t2fit.h.  torch is used for device buffers and streams, nothing else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+from ._lib import check, load, require_gpu
+
+# scipy defaults that apply when a table omits an option (scipy.optimize._lbfgsb_py._minimize_lbfgsb)
+_SCIPY_DEFAULTS = {"ftol": 2.2204460492503131e-09, "gtol": 1e-5, "eps": 1e-8, "maxfun": 15000,
+                   "maxiter": 15000, "maxls": 20, "maxcor": 10}
+
+
+# --------------------------------------------------------------------------------------------
+# fit tables
+# --------------------------------------------------------------------------------------------
+def fit_table(fit: str, low_field: bool) -> dict:
+    """The reference's ``fit_params`` dict for (fit, field), read from the library's tables."""
+    cfg = _abi.T2FitConfig()
+    check(load().t2fit_config_default(C.byref(cfg), _abi.MODELS[fit], int(bool(low_field))))
+    n_par = 2 if fit == "gaussian" else 3
+
+    def _num(v):  # the reference writes ints where it can; keep printing identical
+        return int(v) if float(v).is_integer() else float(v)
+
+    options = {"ftol": cfg.ftol, "maxls": cfg.maxls, "disp": False}
+    if fit != "gaussian":
+        options = {"gtol": cfg.gtol, "ftol": cfg.ftol, "maxls": cfg.maxls, "disp": False}
+    return {
+        "initial_guess": [_num(cfg.x0[j]) for j in range(n_par)],
+        "param_bounds": [(_num(cfg.lb[j]), _num(cfg.ub[j])) for j in range(n_par)],
+        "solver": "L-BFGS-B",
+        "options": options,
+    }
+
+
+def set_fit_params(args):
+    """run_t2mapping.py:29-111: ``args`` carries gaussian/gaussian_rician/rician, lf/hf, norm."""
+    if getattr(args, "norm", False):
+        print("Error: Normalization is set to true though no parameters where defined yet. "
+              "Please modify set_fit_params to manage.")
+        raise SystemExit(1)
+    fit = "gaussian" if args.gaussian else "gaussian_rician" if args.gaussian_rician else "rician"
+    if not (args.lf or args.hf):
+        raise SystemExit(1)
+    return fit, fit_table(fit, bool(args.lf))
+
+
+def make_config(fit: str, fit_params: dict, TEeffs, prior: bool = True, norm: bool = False,
+                solver: str = "lbfgsb", precision: str = "f64") -> _abi.T2FitConfig:
+    """Flatten (fit, fit_params, TEeffs, prior, norm) into the ABI struct."""
+    if fit not in _abi.MODELS:
+        raise ValueError(f"unknown fit {fit!r}")
+    if fit_params.get("solver", "L-BFGS-B") != "L-BFGS-B":
+        raise ValueError("only the reference's solver 'L-BFGS-B' is defined for fit_params['solver']")
+    te = np.asarray(TEeffs, dtype=np.float64).ravel()
+    if not 2 <= te.size <= _abi.MAX_TE:
+        raise ValueError(f"need 2..{_abi.MAX_TE} echo times, got {te.size}")
+    cfg = _abi.T2FitConfig()
+    check(load().t2fit_config_default(C.byref(cfg), _abi.MODELS[fit], 1))
+    n_par = 2 if fit == "gaussian" else 3
+    x0 = list(fit_params["initial_guess"])
+    bounds = list(fit_params["param_bounds"])
+    if len(x0) != n_par:
+        raise ValueError("length of initial_guess does not match the model")
+    if len(bounds) != n_par:
+        raise ValueError("length of x0 != length of bounds")  # scipy's message
+    for j in range(3):
+        cfg.x0[j] = float(x0[j]) if j < n_par else 0.0
+        cfg.lb[j] = float(bounds[j][0]) if j < n_par else 0.0
+        cfg.ub[j] = float(bounds[j][1]) if j < n_par else 0.0
+    opts = dict(_SCIPY_DEFAULTS)
+    opts.update({k: v for k, v in fit_params.get("options", {}).items() if k not in ("disp", "iprint")})
+    if int(opts["maxcor"]) != 10:
+        raise NotImplementedError("the lane solver keeps scipy's default maxcor=10 corrections")
+    if not opts["maxls"] > 0:
+        raise ValueError("maxls must be positive.")
+    cfg.ftol, cfg.gtol, cfg.fd_step = float(opts["ftol"]), float(opts["gtol"]), float(opts["eps"])
+    cfg.maxls, cfg.maxiter, cfg.maxfun = int(opts["maxls"]), int(opts["maxiter"]), int(opts["maxfun"])
+    cfg.n_te = te.size
+    for i in range(_abi.MAX_TE):
+        cfg.te_ms[i] = float(te[i]) if i < te.size else 0.0
+    cfg.no_prior = int(not prior)
+    cfg.norm = int(bool(norm))
+    cfg.solver = _abi.SOLVERS[solver]
+    cfg.precision = _abi.PRECISIONS[precision]
+    if cfg.solver == _abi.SOLVER_LM:
+        cfg.maxiter = 0  # library default for LM
+    return cfg
+
+
+# --------------------------------------------------------------------------------------------
+# stack / mask / flatten
+# --------------------------------------------------------------------------------------------
+def stack_mask_flatten(echo_vols: Sequence[np.ndarray], mask_vols: Sequence[np.ndarray], device: int = 0):
+    """run_t2mapping.py:383-386,411-421 without the (Z,Y,X,nTE) transpose.
+
+    Returns ``(echoes (nTE,N) float32 torch tensor on the GPU, mask (Z,Y,X) bool ndarray,
+    mask_indices (M,) int64 ndarray)``; mask and indices are computed on the device and are
+    bit-identical to ``np.sum(stack(masks),axis=3) > 0`` / ``np.where(...)[0]``.
+    """
+    import torch
+
+    lib = require_gpu()
+    shape = tuple(np.asarray(echo_vols[0]).shape)
+    n = int(np.prod(shape))
+    dev = torch.device("cuda", device)
+    echoes = torch.empty((len(echo_vols), n), dtype=torch.float32, device=dev)
+    for i, v in enumerate(echo_vols):
+        echoes[i] = torch.from_numpy(np.ascontiguousarray(v).astype(np.float32, copy=False).reshape(-1)).to(dev)
+    masks = torch.empty((len(mask_vols), n), dtype=torch.uint8, device=dev)
+    for i, m in enumerate(mask_vols):
+        masks[i] = torch.from_numpy((np.asarray(m) != 0).astype(np.uint8).reshape(-1)).to(dev)
+    mask_d, idx_d, cnt_d = union_mask_dev(masks)
+    count = int(cnt_d.item())
+    return echoes, mask_d.cpu().numpy().astype(bool).reshape(shape), idx_d[:count].cpu().numpy()
+
+
+def union_mask_dev(masks):
+    """(n_masks, N) uint8 cuda tensor -> (mask uint8 [N], idx int64 [N] (first `count` valid), count)."""
+    import torch
+
+    lib = require_gpu()
+    assert masks.is_cuda and masks.dtype == torch.uint8 and masks.is_contiguous() and masks.dim() == 2
+    n = masks.shape[1]
+    mask = torch.empty(n, dtype=torch.uint8, device=masks.device)
+    idx = torch.empty(n, dtype=torch.int64, device=masks.device)
+    cnt = torch.zeros(1, dtype=torch.int64, device=masks.device)
+    with torch.cuda.device(masks.device):
+        st = torch.cuda.current_stream().cuda_stream
+        check(lib.t2fit_union_mask_dev(masks.data_ptr(), masks.shape[0], n, mask.data_ptr(), idx.data_ptr(),
+                                       cnt.data_ptr(), C.c_void_p(st)))
+    return mask, idx, cnt
+
+
+# --------------------------------------------------------------------------------------------
+# volume seam
+# --------------------------------------------------------------------------------------------
+@dataclass
+class T2Maps:
+    """The reference's four maps (utils/t2map_utils.py:18-29) plus optional per-voxel extras."""
+    t2: object
+    k: object
+    sigma: object
+    res: object
+    r2: Optional[object] = None
+    fun: Optional[object] = None
+    nit: Optional[object] = None
+    status: Optional[object] = None
+
+    def success(self):
+        """scipy ``result.success`` per voxel (False outside the mask)."""
+        return None if self.status is None else (self.status == _abi.ST_CONVERGED)
+
+
+def _layout_of(echoes_shape, n_te, layout):
+    if layout in ("te_major", _abi.LAYOUT_TE_MAJOR):
+        if echoes_shape[0] != n_te:
+            raise ValueError(f"te_major echoes need shape (nTE, ...): got {tuple(echoes_shape)} for nTE={n_te}")
+        return _abi.LAYOUT_TE_MAJOR, tuple(echoes_shape[1:])
+    if layout in ("voxel_major", _abi.LAYOUT_VOXEL_MAJOR):
+        if echoes_shape[-1] != n_te:
+            raise ValueError(f"voxel_major echoes need shape (..., nTE): got {tuple(echoes_shape)} for nTE={n_te}")
+        return _abi.LAYOUT_VOXEL_MAJOR, tuple(echoes_shape[:-1])
+    raise ValueError(f"unknown layout {layout!r}")
+
+
+def fit_volume(echoes, mask, TEeffs, fit, fit_params, prior=True, norm=False, *, layout="te_major",
+               solver="lbfgsb", precision="f64", extras=False, strict=True, device=0, out: T2Maps = None):
+    """Fit every masked voxel and return the maps (run_t2mapping.py:411-461).
+
+    ``echoes``: float32 ``(nTE, Z, Y, X)`` (``layout='te_major'``, the per-TE volumes as read) or
+    ``(Z, Y, X, nTE)`` (``'voxel_major'``, the reference's ``t2w``); numpy array or CUDA torch tensor.
+    ``mask``: same spatial shape, non-zero = fit, or None.  Returns :class:`T2Maps` shaped ``(Z,Y,X)``
+    -- numpy for numpy input (host entry point), torch for torch input (device entry point,
+    asynchronous on the current stream).  ``strict``: raise ValueError, as the reference's scipy call
+    does, if a voxel's data-dependent bounds are infeasible (numpy path; the torch path never syncs).
+    """
+    cfg = make_config(fit, fit_params, TEeffs, prior, norm, solver, precision)
+    lib = require_gpu()
+    lay, spatial = _layout_of(echoes.shape, cfg.n_te, layout)
+    n = int(np.prod(spatial)) if len(spatial) else 1
+    is_torch = type(echoes).__module__.startswith("torch")
+    maps = _abi.T2FitMaps()
+    if is_torch:
+        import torch
+
+        if not (echoes.is_cuda and echoes.dtype == torch.float32 and echoes.is_contiguous()):
+            raise ValueError("torch echoes must be a contiguous float32 CUDA tensor")
+        dev = echoes.device
+        if mask is not None:
+            if not (mask.is_cuda and mask.dtype == torch.uint8 and mask.is_contiguous() and mask.numel() == n):
+                raise ValueError("torch mask must be a contiguous uint8 CUDA tensor of the spatial shape")
+        if out is None:
+            f32 = lambda: torch.empty(spatial, dtype=torch.float32, device=dev)  # noqa: E731
+            out = T2Maps(f32(), f32(), f32(), f32())
+            if extras:
+                out.r2, out.fun = f32(), f32()
+                out.nit = torch.empty(spatial, dtype=torch.int32, device=dev)
+                out.status = torch.empty(spatial, dtype=torch.uint8, device=dev)
+        for name in ("t2", "k", "sigma", "res", "r2", "fun", "nit", "status"):
+            t = getattr(out, name)
+            setattr(maps, name, None if t is None else t.data_ptr())
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream().cuda_stream
+            check(lib.t2fit_volume_dev(C.byref(cfg), echoes.data_ptr(), lay,
+                                       None if mask is None else mask.data_ptr(), n, C.byref(maps),
+                                       C.c_void_p(st)))
+        return out
+    e = np.ascontiguousarray(echoes, dtype=np.float32)
+    m = None if mask is None else np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
+    if m is not None and m.size != n:
+        raise ValueError("mask shape does not match the echoes")
+    f32 = lambda: np.empty(spatial, np.float32)  # noqa: E731
+    out = T2Maps(f32(), f32(), f32(), f32())
+    out.status = np.empty(spatial, np.uint8)
+    if extras:
+        out.r2, out.fun, out.nit = f32(), f32(), np.empty(spatial, np.int32)
+    for name in ("t2", "k", "sigma", "res", "r2", "fun", "nit", "status"):
+        a = getattr(out, name)
+        setattr(maps, name, None if a is None else a.ctypes.data)
+    check(lib.t2fit_volume_host(C.byref(cfg), e.ctypes.data, lay, None if m is None else m.ctypes.data, n,
+                                C.byref(maps), int(device)))
+    if strict and np.any(out.status == _abi.ST_INFEASIBLE):
+        bad = int(np.flatnonzero(out.status.reshape(-1) == _abi.ST_INFEASIBLE)[0])
+        raise ValueError("LBFGSB - one of the lower bounds is greater than an upper bound. "
+                         f"(voxel {bad}: S(TE0) exceeds the no-prior upper bound)")
+    if not extras:
+        out.status = None
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# voxel seam
+# --------------------------------------------------------------------------------------------
+def fit_voxels(indices, fit, fit_params, TEeffs, reshaped_t2w, prior, norm, *, solver="lbfgsb",
+               precision="f64", device=0):
+    """Batched ``fit_voxel``: rows ``indices`` of the (N, nTE) float32 stack.
+
+    Returns ``(x (M,n_par) f64, success (M,) bool, nit (M,) int32, fun (M,) f64, status (M,) u8)``.
+    """
+    cfg = make_config(fit, fit_params, TEeffs, prior, norm, solver, precision)
+    lib = require_gpu()
+    data = np.ascontiguousarray(reshaped_t2w, dtype=np.float32)
+    if data.ndim != 2 or data.shape[1] != cfg.n_te:
+        raise ValueError("reshaped_t2w must be (N, nTE)")
+    idx = np.ascontiguousarray(np.atleast_1d(indices), dtype=np.int64)
+    m = idx.size
+    x = np.zeros((m, 3))
+    fun = np.zeros(m)
+    nit = np.zeros(m, np.int32)
+    st = np.zeros(m, np.uint8)
+    check(lib.t2fit_voxels_host(C.byref(cfg), data.ctypes.data, _abi.LAYOUT_VOXEL_MAJOR, data.shape[0],
+                                idx.ctypes.data, m, x.ctypes.data, fun.ctypes.data, nit.ctypes.data,
+                                st.ctypes.data, int(device)))
+    n_par = 2 if fit == "gaussian" else 3
+    return x[:, :n_par], st == _abi.ST_CONVERGED, nit, fun, st
+
+
+def fit_voxel(voxel, fit, fit_params, TEeffs, reshaped_t2w, prior, norm, **kw):
+    """run_t2mapping.py:120-312 for one voxel: ``(params, success, nit, final_error, iteration_info)``.
+
+    Like the reference, a voxel whose no-prior bounds are infeasible raises ValueError, and
+    ``fit_params['param_bounds']`` is rewritten in place when ``prior`` is False (:243-245).
+    ``iteration_info`` is always empty: per-iteration traces feed only the reference's plots.
+    """
+    if not prior:
+        fit_params["param_bounds"][0] = (reshaped_t2w[voxel, 0], 10000)
+        fit_params["param_bounds"][1] = (10, 2000)
+        if fit_params["param_bounds"][0][0] > 10000:
+            raise ValueError("LBFGSB - one of the lower bounds is greater than an upper bound.")
+    x, ok, nit, fun, st = fit_voxels([voxel], fit, fit_params, TEeffs, reshaped_t2w, prior, norm, **kw)
+    if not ok[0]:
+        print(f"FAIL : Optimization failed for voxel {voxel}: status {int(st[0])}")
+        print("Objective function value at optimum:", fun[0])
+        print("params", x[0])
+    return x[0], bool(ok[0]), int(nit[0]), float(fun[0]), []
+
+
+# --------------------------------------------------------------------------------------------
+# residual map
+# --------------------------------------------------------------------------------------------
+def compute_residuals(reshaped_t2w, TEeffs, fit, norm, k_map, t2_map, sigma_map, res_map, mask_indices, mask,
+                      device=0):
+    """utils/t2map_utils.py:62-89 with the reference's signature; evaluated on the GPU."""
+    import torch
+
+    lib = require_gpu()
+    data = np.ascontiguousarray(reshaped_t2w, dtype=np.float32)
+    n, n_te = data.shape
+    cfg = make_config(fit, fit_table(fit, True), TEeffs, True, norm)
+    dev = torch.device("cuda", device)
+    e = torch.from_numpy(data).to(dev)
+    sel = torch.zeros(n, dtype=torch.uint8, device=dev)
+    sel[torch.from_numpy(np.asarray(mask_indices, dtype=np.int64)).to(dev)] = 1
+    t2 = torch.from_numpy(np.ascontiguousarray(t2_map, np.float32).reshape(-1)).to(dev)
+    k = torch.from_numpy(np.ascontiguousarray(k_map, np.float32).reshape(-1)).to(dev)
+    sg = torch.from_numpy(np.ascontiguousarray(sigma_map, np.float32).reshape(-1)).to(dev)
+    res = torch.empty(n, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream().cuda_stream
+        check(lib.t2fit_residuals_dev(C.byref(cfg), e.data_ptr(), _abi.LAYOUT_VOXEL_MAJOR, sel.data_ptr(), n,
+                                      t2.data_ptr(), k.data_ptr(), sg.data_ptr(), res.data_ptr(), C.c_void_p(st)))
+    out = np.asarray(res_map, dtype=np.float32).reshape(-1).copy()
+    r = res.cpu().numpy()
+    mi = np.asarray(mask_indices, dtype=np.int64)
+    out[mi] = r[mi]
+    return out.reshape(np.asarray(mask).shape[:3])
