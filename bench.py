@@ -23,8 +23,30 @@ import os
 import sys
 import time
 
+# one BLAS/OpenMP thread per process, set before numpy loads: the CPU baseline runs one scipy fit
+# per worker process and oversubscribed BLAS threads slow it by >10x
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """Cores this process may actually use: affinity, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("T2FIT_BENCH_CORES", "64"))))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 
@@ -53,9 +75,8 @@ def cpu_baseline(echoes_rows, te, fit, prior, seconds):
 
     from oracle import t2fit_oracle as O
 
-    os.environ["OPENBLAS_NUM_THREADS"] = "1"
-    os.environ["OMP_NUM_THREADS"] = "1"
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
+    log(f"cpu baseline: {cores} worker processes")
     table = O.fit_table(fit, True)
     # calibrate on a few voxels, then size the sample for ~`seconds` of wall time
     t0 = time.perf_counter()
@@ -63,6 +84,7 @@ def cpu_baseline(echoes_rows, te, fit, prior, seconds):
     O.fit_volume(echoes_rows[:probe], np.arange(probe), te, fit, table, prior=prior)
     per_voxel = (time.perf_counter() - t0) / probe
     n = int(min(echoes_rows.shape[0], max(cores * 50, seconds * cores / per_voxel)))
+    log(f"cpu baseline: {per_voxel * 1e3:.2f} ms/voxel single process, timing {n} voxels")
     rows = echoes_rows[:n]
     with mp.get_context("fork").Pool(cores) as pool:
         t0 = time.perf_counter()
@@ -97,6 +119,7 @@ def main():
         ev, mv, te_c = synth.brain_volume((6, a.shape[1], a.shape[2]), a.n_te, synth.SEED_BASE + 3)
         rows = np.ascontiguousarray(ev.reshape(a.n_te, -1)[:, mv.reshape(-1) != 0].T)
         cpu = cpu_baseline(rows, te_c, a.fit, not a.no_prior, a.cpu_seconds)
+    log("cpu baseline done" if cpu else "no cpu baseline")
     lib = require_gpu()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -107,6 +130,7 @@ def main():
     z, y, x = a.shape
     n_vox = z * y * x
     echoes, mask, te = synth.brain_volume_torch((z, y, x), a.n_te, synth.SEED_BASE + 3 + rank, dev)
+    log(f"synthetic slab on device: {n_vox} voxels x {a.n_te} TE")
     table = t2.fit_table(a.fit, True)
     cfg = t2.make_config(a.fit, table, te, prior=not a.no_prior, norm=False, solver=a.solver, precision=a.precision)
     # packed output slab [4, n_vox]: t2, k, sigma, res -- one all-gather moves all four maps
@@ -129,7 +153,8 @@ def main():
 
     for _ in range(a.warmup):
         step(False)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        log("warmup step done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
