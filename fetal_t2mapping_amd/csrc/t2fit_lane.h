@@ -70,7 +70,13 @@ T2_HD float t2_log(float x) { return logf(x); }
 
 template <typename T> T2_HD T t2_min(T a, T b) { return a < b ? a : b; }
 template <typename T> T2_HD T t2_max(T a, T b) { return a > b ? a : b; }
-template <typename T> T2_HD T t2_clip(T x, T lo, T hi) { return t2_min(t2_max(x, lo), hi); }
+// a NaN bound is ignored (a voxel whose S(TE0) is NaN keeps the table start point, as scipy reports it)
+template <typename T> T2_HD T t2_clip(T x, T lo, T hi) {
+  T r = x;
+  if (lo > r) r = lo;
+  if (hi < r) r = hi;
+  return r;
+}
 template <typename T> T2_HD T t2_abs(T a) { return a < T(0) ? -a : a; }
 T2_HD bool t2_finite(double x) { return (x - x) == 0.0; }
 T2_HD bool t2_finite(float x) { return (x - x) == 0.0f; }
@@ -129,6 +135,9 @@ struct ObjCtx {
   EchoView y;
   bool norm;
   float ymax;
+  double* trace = nullptr;  // optional (host simulator only): x, f per iteration, 4 doubles each
+  int trace_cap = 0;
+  int* trace_n = nullptr;
   T2_HD float sample(int i) const { return norm ? y[i] / ymax : y[i]; }
 };
 

@@ -1,17 +1,653 @@
-// t2fit_lbfgsb.h -- placeholder, replaced by the per-lane L-BFGS-B solver.
+// t2fit_lbfgsb.h -- per-lane restatement of the reference's optimiser.
+//
+// The reference fits each voxel with scipy.optimize.minimize(method="L-BFGS-B", jac=False)
+// (run_t2mapping.py:260-286).  scipy is a third-party dependency that is not part of the reference
+// tree (pinned 1.11.3, requirements_frozen.txt:144); this file restates its published algorithm for
+// the 2- and 3-parameter problems of this path so that a lane reproduces the reference's iterates,
+// stop decisions and therefore its (deliberately early-stopped) maps:
+//
+//   * driver and stop rules: scipy _minimize_lbfgsb (x0 clipped into the bounds; factr = ftol/eps;
+//     pgtol = gtol; maxiter / maxfun checked after every iteration)
+//   * gradient: scipy approx_derivative('2-point', abs_step=1e-8, bounds=...): forward difference
+//     with the step flipped or shortened at a bound, dx recomputed as (x+h)-x
+//   * L-BFGS-B 3.0 (Byrd, Lu, Nocedal, Zhu 1995; Zhu, Byrd, Lu, Nocedal 1997; Morales, Nocedal
+//     2011): projected-gradient test, generalized Cauchy point, subspace minimisation with the
+//     projected-Newton refinement and backtracking, More'-Thuente line search (dcsrch/dcstep,
+//     ftol 1e-3, gtol 0.9, xtol 0.1, <= maxls evaluations), curvature test s'y > eps*(-g's),
+//     theta = y'y / s'y, m = 10 correction pairs.
+//
+// What is different from the library code, and why: with n <= 3 variables the limited-memory
+// matrix B = theta*I - W M W' is formed explicitly (n x n) by applying the stored pairs as BFGS
+// updates to theta*I (Byrd-Nocedal-Schnabel 1994, thm 2.3: identical in exact arithmetic), so the
+// 2m x 2m middle matrices of the general code never exist and the whole state of a lane -- 10 pairs
+// of 3-vectors -- stays in registers.  Consequently the library's numerical-breakdown restarts
+// (Cholesky failure inside formk/formt) are replaced by a positive-definiteness check of the reduced
+// n x n system.  Everything is float64, as in the reference.
 #pragma once
 
 #include "t2fit_lane.h"
 
+#if defined(__HIPCC__)
+#define T2_UNROLL _Pragma("unroll")
+#else
+#define T2_UNROLL
+#endif
+
 namespace t2fit {
+
+// ---- objective with numpy's summation order --------------------------------------------------
+// np.sum over a contiguous float64 vector: sequential for n < 8, otherwise eight interleaved
+// partial sums combined as a balanced tree plus a sequential tail (numpy pairwise_sum).
+template <int MODEL> struct ObjTerm;
+template <> struct ObjTerm<T2FIT_MODEL_GAUSSIAN> {
+  double k, t2;
+  T2_HD void set(const double* x) { k = x[0]; t2 = x[1]; }
+  T2_HD double at(const ObjCtx& c, int i) const {
+    const double r = (double)c.sample(i) - k * t2_exp(-c.P->te[i] / t2);
+    return r * r;
+  }
+  T2_HD double finish(const ObjCtx& c, double s) const { return s / c.P->n_te; }
+};
+template <> struct ObjTerm<T2FIT_MODEL_GAUSSIAN_RICIAN> {
+  double k2, t2, s2;
+  T2_HD void set(const double* x) { k2 = x[0] * x[0]; t2 = x[1]; s2 = x[2] * x[2]; }
+  T2_HD double at(const ObjCtx& c, int i) const {
+    const double r = (double)c.sample(i) - t2_sqrt(k2 * t2_exp(-2.0 * c.P->te[i] / t2) + s2);
+    return r * r;
+  }
+  T2_HD double finish(const ObjCtx& c, double s) const { return s / c.P->n_te; }
+};
+template <> struct ObjTerm<T2FIT_MODEL_RICIAN> {
+  double k, t2, s2, ls2;
+  T2_HD void set(const double* x) { k = x[0]; t2 = x[1]; s2 = x[2] * x[2]; ls2 = t2_log(s2); }
+  T2_HD double at(const ObjCtx& c, int i) const {
+    const float yf = c.sample(i);
+    const double m = k * t2_exp(-c.P->te[i] / t2);
+    const double xx = (m * (double)yf) / s2;
+    const double a = (double)logf(yf) - ls2;
+    const double b = ((double)(yf * yf) + m * m) / (2.0 * s2);
+    const double d = (xx < 0 ? -xx : xx) + t2_log(t2_i0e(xx));
+    return (a - b) + d;
+  }
+  T2_HD double finish(const ObjCtx&, double s) const { return -s; }
+};
+
+template <int MODEL>
+T2_HD double objective_t(const ObjCtx& c, const double* x) {
+  ObjTerm<MODEL> t;
+  t.set(x);
+  const int n = c.P->n_te;
+  double s;
+  if (n < 8) {
+    s = 0.0;
+    for (int i = 0; i < n; ++i) s += t.at(c, i);
+  } else {
+    double r[8];
+    T2_UNROLL
+    for (int j = 0; j < 8; ++j) r[j] = t.at(c, j);
+    int i = 8;
+    for (; i + 8 <= n; i += 8) {
+      T2_UNROLL
+      for (int j = 0; j < 8; ++j) r[j] += t.at(c, i + j);
+    }
+    s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) s += t.at(c, i);
+  }
+  return t.finish(c, s);
+}
+
+// ---- More'-Thuente line search (MINPACK-2 dcsrch / dcstep) ------------------------------------
+enum { LS_START = 0, LS_FG = 1, LS_CONV = 2, LS_WARN = 3, LS_ERROR = 4 };
+
+struct LsState {
+  int task, stage;
+  bool brackt;
+  double ginit, gtest, gx, gy, finit, fx, fy, stx, sty, stmin, stmax, width, width1;
+};
+
+T2_HD double t2_max3(double a, double b, double c) { return t2_max(a, t2_max(b, c)); }
+
+T2_HD void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy, double& dy, double& stp,
+                  double fp, double dp, bool& brackt, double stpmin, double stpmax) {
+  const double sgnd = dp * (dx / t2_abs(dx));
+  double stpf;
+  if (fp > fx) {  // case 1: higher function value -> minimum bracketed
+    const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    const double s = t2_max3(t2_abs(theta), t2_abs(dx), t2_abs(dp));
+    double gamma = s * t2_sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+    if (stp < stx) gamma = -gamma;
+    const double p = (gamma - dx) + theta;
+    const double q = ((gamma - dx) + gamma) + dp;
+    const double r = p / q;
+    const double stpc = stx + r * (stp - stx);
+    const double stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.0) * (stp - stx);
+    if (t2_abs(stpc - stx) < t2_abs(stpq - stx)) stpf = stpc;
+    else stpf = stpc + (stpq - stpc) / 2.0;
+    brackt = true;
+  } else if (sgnd < 0.0) {  // case 2: derivatives of opposite sign
+    const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    const double s = t2_max3(t2_abs(theta), t2_abs(dx), t2_abs(dp));
+    double gamma = s * t2_sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+    if (stp > stx) gamma = -gamma;
+    const double p = (gamma - dp) + theta;
+    const double q = ((gamma - dp) + gamma) + dx;
+    const double r = p / q;
+    const double stpc = stp + r * (stx - stp);
+    const double stpq = stp + (dp / (dp - dx)) * (stx - stp);
+    if (t2_abs(stpc - stp) > t2_abs(stpq - stp)) stpf = stpc;
+    else stpf = stpq;
+    brackt = true;
+  } else if (t2_abs(dp) < t2_abs(dx)) {  // case 3: derivative magnitude decreases
+    const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    const double s = t2_max3(t2_abs(theta), t2_abs(dx), t2_abs(dp));
+    double gamma = s * t2_sqrt(t2_max(0.0, (theta / s) * (theta / s) - (dx / s) * (dp / s)));
+    if (stp > stx) gamma = -gamma;
+    const double p = (gamma - dp) + theta;
+    const double q = (gamma + (dx - dp)) + gamma;
+    const double r = p / q;
+    double stpc;
+    if (r < 0.0 && gamma != 0.0) stpc = stp + r * (stx - stp);
+    else if (stp > stx) stpc = stpmax;
+    else stpc = stpmin;
+    const double stpq = stp + (dp / (dp - dx)) * (stx - stp);
+    if (brackt) {
+      if (t2_abs(stpc - stp) < t2_abs(stpq - stp)) stpf = stpc;
+      else stpf = stpq;
+      if (stp > stx) stpf = t2_min(stp + 0.66 * (sty - stp), stpf);
+      else stpf = t2_max(stp + 0.66 * (sty - stp), stpf);
+    } else {
+      if (t2_abs(stpc - stp) > t2_abs(stpq - stp)) stpf = stpc;
+      else stpf = stpq;
+      stpf = t2_min(stpmax, stpf);
+      stpf = t2_max(stpmin, stpf);
+    }
+  } else {  // case 4: derivative does not decrease
+    if (brackt) {
+      const double theta = 3.0 * (fp - fy) / (sty - stp) + dy + dp;
+      const double s = t2_max3(t2_abs(theta), t2_abs(dy), t2_abs(dp));
+      double gamma = s * t2_sqrt((theta / s) * (theta / s) - (dy / s) * (dp / s));
+      if (stp > sty) gamma = -gamma;
+      const double p = (gamma - dp) + theta;
+      const double q = ((gamma - dp) + gamma) + dy;
+      const double r = p / q;
+      stpf = stp + r * (sty - stp);
+    } else if (stp > stx) {
+      stpf = stpmax;
+    } else {
+      stpf = stpmin;
+    }
+  }
+  if (fp > fx) {
+    sty = stp; fy = fp; dy = dp;
+  } else {
+    if (sgnd < 0.0) { sty = stx; fy = fx; dy = dx; }
+    stx = stp; fx = fp; dx = dp;
+  }
+  stp = stpf;
+}
+
+T2_HD void dcsrch(double f, double g, double& stp, double ftol, double gtol, double xtol, double stpmin,
+                  double stpmax, LsState& s) {
+  const double xtrapl = 1.1, xtrapu = 4.0, p5 = 0.5, p66 = 0.66;
+  if (s.task == LS_START) {
+    if (stp < stpmin || stp > stpmax || g >= 0.0) { s.task = LS_ERROR; return; }
+    s.brackt = false;
+    s.stage = 1;
+    s.finit = f; s.ginit = g; s.gtest = ftol * s.ginit;
+    s.width = stpmax - stpmin; s.width1 = s.width / p5;
+    s.stx = 0.0; s.fx = s.finit; s.gx = s.ginit;
+    s.sty = 0.0; s.fy = s.finit; s.gy = s.ginit;
+    s.stmin = 0.0; s.stmax = stp + xtrapu * stp;
+    s.task = LS_FG;
+    return;
+  }
+  const double ftest = s.finit + stp * s.gtest;
+  if (s.stage == 1 && f <= ftest && g >= 0.0) s.stage = 2;
+  int task = LS_FG;
+  if (s.brackt && (stp <= s.stmin || stp >= s.stmax)) task = LS_WARN;   // rounding errors prevent progress
+  if (s.brackt && s.stmax - s.stmin <= xtol * s.stmax) task = LS_WARN;  // xtol test satisfied
+  if (stp == stpmax && f <= ftest && g <= s.gtest) task = LS_WARN;      // stp = stpmax
+  if (stp == stpmin && (f > ftest || g >= s.gtest)) task = LS_WARN;     // stp = stpmin
+  if (f <= ftest && t2_abs(g) <= gtol * (-s.ginit)) task = LS_CONV;
+  if (task != LS_FG) { s.task = task; return; }
+  if (s.stage == 1 && f <= s.fx && f > ftest) {
+    const double fm = f - stp * s.gtest;
+    double fxm = s.fx - s.stx * s.gtest, fym = s.fy - s.sty * s.gtest;
+    const double gm = g - s.gtest;
+    double gxm = s.gx - s.gtest, gym = s.gy - s.gtest;
+    dcstep(s.stx, fxm, gxm, s.sty, fym, gym, stp, fm, gm, s.brackt, s.stmin, s.stmax);
+    s.fx = fxm + s.stx * s.gtest;
+    s.fy = fym + s.sty * s.gtest;
+    s.gx = gxm + s.gtest;
+    s.gy = gym + s.gtest;
+  } else {
+    dcstep(s.stx, s.fx, s.gx, s.sty, s.fy, s.gy, stp, f, g, s.brackt, s.stmin, s.stmax);
+  }
+  if (s.brackt) {
+    if (t2_abs(s.sty - s.stx) >= p66 * s.width1) stp = s.stx + p5 * (s.sty - s.stx);
+    s.width1 = s.width;
+    s.width = t2_abs(s.sty - s.stx);
+  }
+  if (s.brackt) {
+    s.stmin = t2_min(s.stx, s.sty);
+    s.stmax = t2_max(s.stx, s.sty);
+  } else {
+    s.stmin = stp + xtrapl * (stp - s.stx);
+    s.stmax = stp + xtrapu * (stp - s.stx);
+  }
+  stp = t2_max(stp, stpmin);
+  stp = t2_min(stp, stpmax);
+  if ((s.brackt && (stp <= s.stmin || stp >= s.stmax)) || (s.brackt && s.stmax - s.stmin <= xtol * s.stmax))
+    stp = s.stx;
+  s.task = LS_FG;
+}
+
+// ---- the solver -----------------------------------------------------------------------------------
+template <int MODEL>
+struct Lbfgsb {
+  static constexpr int N = MODEL == T2FIT_MODEL_GAUSSIAN ? 2 : 3;
+  static constexpr int M = 10;
+
+  const ObjCtx& c;
+  const double* lb;
+  const double* ub;
+  int nfev;
+
+  T2_HD Lbfgsb(const ObjCtx& c_, const double* lb_, const double* ub_) : c(c_), lb(lb_), ub(ub_), nfev(0) {}
+
+  // scipy ScalarFunction.fun_and_grad with approx_derivative('2-point', abs_step=h, bounds)
+  T2_HD void fg(const double* x, double& f, double* g) {
+    f = objective_t<MODEL>(c, x);
+    const double h0 = c.P->fd_step;
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) {
+      double h = h0;
+      if ((x[i] + h) - x[i] == 0.0)  // step lost to rounding: scipy falls back to sqrt(eps) relative
+        h = 1.4901161193847656e-08 * (x[i] >= 0 ? 1.0 : -1.0) * t2_max(1.0, t2_abs(x[i]));
+      const double lower = x[i] - lb[i], upper = ub[i] - x[i];
+      const double xs = x[i] + h;
+      const bool violated = xs < lb[i] || xs > ub[i];
+      const bool fitting = t2_abs(h) <= t2_max(lower, upper);
+      if (violated && fitting) h = -h;
+      if (!fitting) h = upper >= lower ? upper : -lower;
+      double x1[N];
+      T2_UNROLL
+      for (int j = 0; j < N; ++j) x1[j] = x[j];
+      x1[i] = x[i] + h;
+      const double dx = x1[i] - x[i];
+      const double df = objective_t<MODEL>(c, x1) - f;
+      g[i] = df / dx;
+    }
+    nfev += 1 + N;
+  }
+
+  T2_HD double projgr(const double* x, const double* g) const {
+    double nrm = 0.0;
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) {
+      double gi = g[i];
+      if (gi < 0.0) gi = t2_max(x[i] - ub[i], gi);
+      else gi = t2_min(x[i] - lb[i], gi);
+      nrm = t2_max(nrm, t2_abs(gi));
+    }
+    return nrm;
+  }
+
+  // B = theta*I updated by the stored pairs, oldest first.
+  T2_HD static void build_b(double theta, const double (*S)[N], const double (*Y)[N], int col, double (*B)[N]) {
+    T2_UNROLL
+    for (int i = 0; i < N; ++i)
+      T2_UNROLL
+      for (int j = 0; j < N; ++j) B[i][j] = i == j ? theta : 0.0;
+    T2_UNROLL
+    for (int p = 0; p < M; ++p) {
+      if (p < col) {
+        double bs[N];
+        double sbs = 0.0, ys = 0.0;
+        T2_UNROLL
+        for (int i = 0; i < N; ++i) {
+          double a = 0.0;
+          T2_UNROLL
+          for (int j = 0; j < N; ++j) a += B[i][j] * S[p][j];
+          bs[i] = a;
+        }
+        T2_UNROLL
+        for (int i = 0; i < N; ++i) { sbs += S[p][i] * bs[i]; ys += Y[p][i] * S[p][i]; }
+        T2_UNROLL
+        for (int i = 0; i < N; ++i)
+          T2_UNROLL
+          for (int j = 0; j < N; ++j) B[i][j] += Y[p][i] * Y[p][j] / ys - bs[i] * bs[j] / sbs;
+      }
+    }
+  }
+
+  // Generalized Cauchy point along the projected steepest-descent path.
+  T2_HD void cauchy(const double* x, const double* g, const double (*B)[N], double theta, double sbgnrm,
+                    int* iwhere, double* xcp) const {
+    const double epsmch = 2.220446049250313e-16;
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) xcp[i] = x[i];
+    if (sbgnrm <= 0.0) return;
+    double d[N], tbk[N], zfix[N];
+    bool hasbk[N];
+    int nbreak = 0;
+    double f1 = 0.0;
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) {
+      const double neggi = -g[i];
+      const double tl = x[i] - lb[i], tu = ub[i] - x[i];
+      if (iwhere[i] != 3) {
+        const bool xlower = tl <= 0.0, xupper = tu <= 0.0;
+        iwhere[i] = 0;
+        if (xlower) { if (neggi <= 0.0) iwhere[i] = 1; }
+        else if (xupper) { if (neggi >= 0.0) iwhere[i] = 2; }
+        else if (t2_abs(neggi) <= 0.0) iwhere[i] = -3;
+      }
+      d[i] = 0.0; tbk[i] = 0.0; zfix[i] = 0.0; hasbk[i] = false;
+      if (iwhere[i] == 0) {
+        d[i] = neggi;
+        f1 -= neggi * neggi;
+        if (neggi < 0.0) { tbk[i] = tl / (-neggi); hasbk[i] = true; ++nbreak; }
+        else if (neggi > 0.0) { tbk[i] = tu / neggi; hasbk[i] = true; ++nbreak; }
+      }
+    }
+    if (nbreak == 0) return;  // every moving variable is box-bounded here, so d == 0
+    const double f2_org = -theta * f1;
+    auto dBd = [&](const double* dd) {
+      double s = 0.0;
+      T2_UNROLL
+      for (int i = 0; i < N; ++i)
+        T2_UNROLL
+        for (int j = 0; j < N; ++j) s += dd[i] * B[i][j] * dd[j];
+      return s;
+    };
+    double f2 = dBd(d);
+    double dtm = -f1 / f2;
+    double tsum = 0.0, tj = 0.0;
+    int nleft = nbreak;
+    bool all_fixed = false;
+    while (nleft > 0) {
+      int ibp = -1;
+      double tmin = 0.0;
+      T2_UNROLL
+      for (int i = 0; i < N; ++i)
+        if (hasbk[i] && (ibp < 0 || tbk[i] < tmin)) { ibp = i; tmin = tbk[i]; }
+      const double tj0 = tj;
+      tj = tmin;
+      const double dt = tj - tj0;
+      if (dtm < dt) break;
+      tsum += dt;
+      --nleft;
+      double dibp = 0.0;
+      T2_UNROLL
+      for (int i = 0; i < N; ++i)
+        if (i == ibp) {
+          dibp = d[i];
+          d[i] = 0.0;
+          hasbk[i] = false;
+          if (dibp > 0.0) { zfix[i] = ub[i] - x[i]; xcp[i] = ub[i]; iwhere[i] = 2; }
+          else { zfix[i] = lb[i] - x[i]; xcp[i] = lb[i]; iwhere[i] = 1; }
+        }
+      if (nleft == 0 && nbreak == N) { all_fixed = true; break; }
+      // derivatives of the quadratic model along the remaining direction, z = xcp - x so far
+      double z[N];
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) z[i] = d[i] != 0.0 ? tsum * d[i] : zfix[i];
+      f1 = 0.0;
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) {
+        double bz = 0.0;
+        T2_UNROLL
+        for (int j = 0; j < N; ++j) bz += B[i][j] * z[j];
+        f1 += d[i] * (g[i] + bz);
+      }
+      f2 = t2_max(epsmch * f2_org, dBd(d));
+      if (nleft > 0) dtm = -f1 / f2;
+      else { f1 = 0.0; f2 = 0.0; dtm = 0.0; }  // all remaining variables are box-bounded
+    }
+    if (all_fixed) return;
+    dtm = t2_max(dtm, 0.0);
+    tsum += dtm;
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) xcp[i] += tsum * d[i];
+  }
+
+  // Direct primal subspace minimisation over the variables free at the Cauchy point, followed by
+  // the L-BFGS-B 3.0 projection / backtracking safeguard.  Returns false if the reduced matrix is
+  // not positive definite.  z holds xcp on entry and the subspace minimiser on exit.
+  T2_HD bool subsm(const double* x, const double* g, const double (*B)[N], const int* iwhere, double* z) const {
+    bool fr[N];
+    double r[N], du[N];
+    int nfree = 0;
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) { fr[i] = iwhere[i] <= 0; nfree += fr[i]; du[i] = 0.0; }
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) {
+      double bz = 0.0;
+      T2_UNROLL
+      for (int j = 0; j < N; ++j) bz += B[i][j] * (z[j] - x[j]);
+      r[i] = fr[i] ? -(g[i] + bz) : 0.0;
+    }
+    // reduced system A du = r with A = B on free rows/cols, identity elsewhere; LDL^T, pivots must be > 0
+    double A[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    T2_UNROLL
+    for (int i = 0; i < N; ++i)
+      T2_UNROLL
+      for (int j = 0; j < N; ++j)
+        if (fr[i] && fr[j]) A[i][j] = B[i][j];
+    double rr[3] = {r[0], r[1], N == 3 ? r[N - 1] : 0.0};
+    if (N == 2) rr[2] = 0.0;
+    const double d0 = A[0][0];
+    if (!(d0 > 0.0)) return false;
+    const double l10 = A[1][0] / d0, l20 = A[2][0] / d0;
+    const double d1 = A[1][1] - l10 * A[1][0];
+    if (!(d1 > 0.0)) return false;
+    const double l21 = (A[2][1] - l20 * A[1][0]) / d1;
+    const double d2 = A[2][2] - l20 * A[2][0] - l21 * (A[2][1] - l20 * A[1][0]);
+    if (!(d2 > 0.0)) return false;
+    const double y0 = rr[0], y1 = rr[1] - l10 * y0, y2 = rr[2] - l20 * y0 - l21 * y1;
+    const double u2 = y2 / d2, u1 = y1 / d1 - l21 * u2, u0 = y0 / d0 - l10 * u1 - l20 * u2;
+    du[0] = u0; du[1] = u1;
+    if (N == 3) du[N - 1] = u2;
+    // projected Newton point
+    double xp[N];
+    bool projected = false;
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) {
+      xp[i] = z[i];
+      if (fr[i]) {
+        const double xk = t2_max(lb[i], z[i] + du[i]);
+        z[i] = t2_min(ub[i], xk);
+        if (z[i] == lb[i] || z[i] == ub[i]) projected = true;
+      }
+    }
+    if (!projected) return true;
+    double ddp = 0.0;
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) ddp += (z[i] - x[i]) * g[i];
+    if (ddp > 0.0) {  // not a descent direction: backtrack along du from the Cauchy point instead
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) z[i] = xp[i];
+      double alpha = 1.0, temp1 = 1.0;
+      int ibd = -1;
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) {
+        if (fr[i]) {
+          const double dk = du[i];
+          if (dk < 0.0) {
+            const double temp2 = lb[i] - z[i];
+            if (temp2 >= 0.0) temp1 = 0.0;
+            else if (dk * alpha < temp2) temp1 = temp2 / dk;
+          } else if (dk > 0.0) {
+            const double temp2 = ub[i] - z[i];
+            if (temp2 <= 0.0) temp1 = 0.0;
+            else if (dk * alpha > temp2) temp1 = temp2 / dk;
+          }
+          if (temp1 < alpha) { alpha = temp1; ibd = i; }
+        }
+      }
+      if (alpha < 1.0) {
+        T2_UNROLL
+        for (int i = 0; i < N; ++i)
+          if (i == ibd) {
+            if (du[i] > 0.0) { z[i] = ub[i]; du[i] = 0.0; }
+            else if (du[i] < 0.0) { z[i] = lb[i]; du[i] = 0.0; }
+          }
+      }
+      T2_UNROLL
+      for (int i = 0; i < N; ++i)
+        if (fr[i]) z[i] += alpha * du[i];
+    }
+    return true;
+  }
+
+  T2_HD void run(LaneResult& out) {
+    const LaneParams& P = *c.P;
+    const double epsmch = 2.220446049250313e-16;
+    const double tol = (P.ftol / epsmch) * epsmch;  // factr * epsmch
+    const double pgtol = P.gtol;
+    double x[N], g[N], f;
+    int iwhere[N];
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) {
+      x[i] = t2_clip(P.x0[i], lb[i], ub[i]);
+      iwhere[i] = (ub[i] - lb[i] <= 0.0) ? 3 : 0;
+    }
+    double S[M][N], Y[M][N];
+    T2_UNROLL
+    for (int p = 0; p < M; ++p)
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) { S[p][i] = 0.0; Y[p][i] = 0.0; }
+    int col = 0, nit = 0;
+    double theta = 1.0;
+    uint8_t status = T2FIT_ST_NOT_CONV;
+    fg(x, f, g);
+    double sbgnrm = projgr(x, g);
+    bool done = sbgnrm <= pgtol;
+    if (done) status = T2FIT_ST_CONVERGED;
+    while (!done) {
+      double B[N][N];
+      build_b(theta, S, Y, col, B);
+      double z[N];
+      cauchy(x, g, B, theta, sbgnrm, iwhere, z);
+      int nfree = 0;
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) nfree += iwhere[i] <= 0;
+      if (nfree != 0 && col != 0) {
+        if (!subsm(x, g, B, iwhere, z)) {  // numerical breakdown: drop the memory, redo the iteration
+          col = 0; theta = 1.0;
+          continue;
+        }
+      }
+      // ---- line search along d = z - x (lnsrlb) ----
+      double d[N], t[N], r[N];
+      double dtd = 0.0;
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) { d[i] = z[i] - x[i]; dtd += d[i] * d[i]; t[i] = x[i]; r[i] = g[i]; }
+      double stpmx = 1e10;
+      if (nit == 0) {
+        stpmx = 1.0;
+      } else {
+        T2_UNROLL
+        for (int i = 0; i < N; ++i) {
+          const double a1 = d[i];
+          if (a1 < 0.0) {
+            const double a2 = lb[i] - x[i];
+            if (a2 >= 0.0) stpmx = 0.0;
+            else if (a1 * stpmx < a2) stpmx = a2 / a1;
+          } else if (a1 > 0.0) {
+            const double a2 = ub[i] - x[i];
+            if (a2 <= 0.0) stpmx = 0.0;
+            else if (a1 * stpmx > a2) stpmx = a2 / a1;
+          }
+        }
+      }
+      double stp = 1.0;  // every variable is boxed, so the first step is not rescaled by 1/|d|
+      const double fold = f;
+      double gd = 0.0, gdold = 0.0;
+      int ifun = 0;
+      bool ls_fail = false;
+      LsState ls;
+      ls.task = LS_START;
+      for (;;) {
+        gd = 0.0;
+        T2_UNROLL
+        for (int i = 0; i < N; ++i) gd += g[i] * d[i];
+        if (ifun == 0) {
+          gdold = gd;
+          if (gd >= 0.0) { ls_fail = true; break; }  // not a descent direction
+        }
+        dcsrch(f, gd, stp, 1e-3, 0.9, 0.1, 0.0, stpmx, ls);
+        if (ls.task == LS_CONV || ls.task == LS_WARN) break;
+        if (ls.task == LS_ERROR) { ls_fail = true; break; }
+        ++ifun;
+        if (ifun - 1 >= P.maxls) { ls_fail = true; break; }
+        T2_UNROLL
+        for (int i = 0; i < N; ++i) x[i] = stp == 1.0 ? z[i] : stp * d[i] + t[i];
+        fg(x, f, g);
+      }
+      if (ls_fail) {
+        T2_UNROLL
+        for (int i = 0; i < N; ++i) { x[i] = t[i]; g[i] = r[i]; }
+        f = fold;
+        if (col == 0) break;  // abnormal termination in the line search: success False
+        col = 0; theta = 1.0;
+        continue;
+      }
+      ++nit;
+#if !defined(__HIP_DEVICE_COMPILE__)
+      if (c.trace && *c.trace_n < c.trace_cap) {
+        double* tr = c.trace + 4 * (*c.trace_n)++;
+        tr[0] = x[0]; tr[1] = x[1]; tr[2] = N == 3 ? x[N - 1] : 0.0; tr[3] = f;
+      }
+#endif
+      sbgnrm = projgr(x, g);
+      if (nit >= P.maxiter || nfev > P.maxfun) break;  // scipy: STOP, success False
+      if (sbgnrm <= pgtol) { status = T2FIT_ST_CONVERGED; break; }
+      if ((fold - f) <= tol * t2_max3(t2_abs(fold), t2_abs(f), 1.0)) { status = T2FIT_ST_CONVERGED; break; }
+      // ---- correction pair ----
+      double rr = 0.0, dr, ddum;
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) { r[i] = g[i] - r[i]; rr += r[i] * r[i]; }
+      if (stp == 1.0) {
+        dr = gd - gdold;
+        ddum = -gdold;
+      } else {
+        dr = (gd - gdold) * stp;
+        T2_UNROLL
+        for (int i = 0; i < N; ++i) d[i] *= stp;
+        ddum = -gdold * stp;
+      }
+      if (dr <= epsmch * ddum) continue;  // curvature too small: skip the update
+      if (col == M) {
+        T2_UNROLL
+        for (int p = 0; p + 1 < M; ++p)
+          T2_UNROLL
+          for (int i = 0; i < N; ++i) { S[p][i] = S[p + 1][i]; Y[p][i] = Y[p + 1][i]; }
+        col = M - 1;
+      }
+      T2_UNROLL
+      for (int p = 0; p < M; ++p)
+        if (p == col)
+          T2_UNROLL
+          for (int i = 0; i < N; ++i) { S[p][i] = d[i]; Y[p][i] = r[i]; }
+      ++col;
+      theta = rr / dr;
+    }
+    T2_UNROLL
+    for (int i = 0; i < 3; ++i) out.x[i] = 0.0;
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) out.x[i] = x[i];
+    out.fun = f;
+    out.nit = nit;
+    out.status = status;
+  }
+};
 
 template <int MODEL>
 T2_HD void lbfgsb_solve(const ObjCtx& c, const double* lb, const double* ub, LaneResult& out) {
-  const int np = n_params(c.P->model);
-  for (int j = 0; j < 3; ++j) out.x[j] = j < np ? t2_clip(c.P->x0[j], lb[j], ub[j]) : 0.0;
-  out.fun = objective(c, out.x);
-  out.nit = 0;
-  out.status = T2FIT_ST_NOT_CONV;
+  Lbfgsb<MODEL> s(c, lb, ub);
+  s.run(out);
 }
 
 }  // namespace t2fit

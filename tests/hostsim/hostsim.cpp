@@ -33,3 +33,39 @@ extern "C" int hostsim_fit_rows(const t2fit_config* cfg, const float* rows, int6
   }
   return 0;
 }
+
+// one voxel with a per-iteration trace (x0, x1, x2, f) for debugging solver trajectories
+extern "C" int hostsim_trace_row(const t2fit_config* cfg, const float* row, double* trace, int cap, int* n_out,
+                                 double* x, double* fun, int32_t* nit, uint8_t* status) {
+  const char* why;
+  int rc = config_check(cfg, &why);
+  if (rc != T2FIT_OK) return rc;
+  const LaneParams P = make_lane_params(*cfg);
+  EchoView y{row, 1};
+  bool finite;
+  ObjCtx c = make_ctx(P, y, finite);
+  *n_out = 0;
+  c.trace = trace; c.trace_cap = cap; c.trace_n = n_out;
+  double lb[3], ub[3];
+  if (!lane_bounds(P, y[0], lb, ub) || !finite) return -10;
+  LaneResult r;
+  if (P.model == T2FIT_MODEL_GAUSSIAN) lbfgsb_solve<T2FIT_MODEL_GAUSSIAN>(c, lb, ub, r);
+  else if (P.model == T2FIT_MODEL_GAUSSIAN_RICIAN) lbfgsb_solve<T2FIT_MODEL_GAUSSIAN_RICIAN>(c, lb, ub, r);
+  else lbfgsb_solve<T2FIT_MODEL_RICIAN>(c, lb, ub, r);
+  for (int j = 0; j < 3; ++j) x[j] = r.x[j];
+  *fun = r.fun; *nit = r.nit; *status = r.status;
+  return 0;
+}
+
+// residual map value per row from given float32 parameters (utils/t2map_utils.py:62-89 per lane)
+extern "C" int hostsim_residuals(const t2fit_config* cfg, const float* rows, int64_t n, const float* k,
+                                 const float* t2, const float* sigma, float* res) {
+  const LaneParams P = make_lane_params(*cfg);
+  for (int64_t v = 0; v < n; ++v) {
+    EchoView y{rows + v * cfg->n_te, 1};
+    bool finite;
+    const ObjCtx c = make_ctx(P, y, finite);
+    res[v] = residual_mean(c, k[v], t2[v], sigma[v]);
+  }
+  return 0;
+}

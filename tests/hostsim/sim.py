@@ -66,3 +66,30 @@ def fit_rows(cfg, rows):
     if rc != 0:
         raise RuntimeError(f"hostsim_fit_rows rc={rc}")
     return {"x": x, "fun": fun, "nit": nit, "status": st, "res": res, "r2": r2}
+
+
+def trace_row(cfg, row, cap=200):
+    row = np.ascontiguousarray(row, np.float32)
+    tr = np.zeros((cap, 4))
+    n = C.c_int(0)
+    x = np.zeros(3)
+    fun = C.c_double(0)
+    nit = C.c_int32(0)
+    st = C.c_uint8(0)
+    L = lib()
+    L.hostsim_trace_row.argtypes = [C.POINTER(_abi.T2FitConfig), C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int),
+                                    C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)]
+    rc = L.hostsim_trace_row(C.byref(cfg), row.ctypes.data, tr.ctypes.data, cap, C.byref(n), x.ctypes.data,
+                             C.byref(fun), C.byref(nit), C.byref(st))
+    return rc, tr[: n.value], x, fun.value, nit.value, st.value
+
+
+def residuals(cfg, rows, k, t2, sigma):
+    rows = np.ascontiguousarray(rows, np.float32)
+    k, t2, sigma = (np.ascontiguousarray(a, np.float32) for a in (k, t2, sigma))
+    res = np.zeros(rows.shape[0], np.float32)
+    L = lib()
+    L.hostsim_residuals.argtypes = [C.POINTER(_abi.T2FitConfig), C.c_void_p, C.c_int64] + [C.c_void_p] * 4
+    L.hostsim_residuals(C.byref(cfg), rows.ctypes.data, rows.shape[0], k.ctypes.data, t2.ctypes.data,
+                        sigma.ctypes.data, res.ctypes.data)
+    return res

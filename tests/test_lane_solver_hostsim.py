@@ -1,0 +1,62 @@
+"""CPU checks of the per-lane solver logic through the host-side lane simulator
+(tests/hostsim: the same headers the HIP kernels are compiled from, built with g++).
+The simulator is test infrastructure only -- the product package has no CPU path."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from hostsim import sim
+
+FILES = sorted(glob.glob(os.path.join(GOLDEN, "voxels_*.npz")))
+PICK = [f for f in FILES if os.path.basename(f)[7:-4] in (
+    "lf_gaussian_prior_te3", "hf_gaussian_noprior_te6", "lf_gaussian_rician_prior_te8",
+    "hf_gaussian_rician_noprior_te3", "lf_rician_prior_te6", "hf_rician_noprior_te8")]
+
+
+@pytest.mark.parametrize("path", PICK, ids=lambda p: os.path.basename(p)[7:-4])
+def test_lbfgsb_lane_solver_tracks_reference(path):
+    d = np.load(path)
+    floor = np.load(os.path.join(GOLDEN, "noise_floor.npz"))
+    name = os.path.basename(path)[7:-4]
+    cfg = sim.config(str(d["mode"]), bool(d["low_field"]), d["te"], prior=bool(d["prior"]), solver="lbfgsb")
+    o = sim.fit_rows(cfg, d["y"])
+    assert np.array_equal(o["status"] == 4, d["raised"])
+    fit = ~d["raised"] & np.isfinite(d["fun"])
+    dt = np.abs(o["x"][fit, 1] - d["x"][fit, 1])
+    assert np.mean(dt <= 1.0) >= min(0.99, float(floor[name + "/frac_1ms"]) - 0.04)
+    assert np.median(dt) <= 0.02
+    assert np.mean((o["status"][fit] == 1) == d["success"][fit]) >= 0.99
+    bad = ~d["raised"] & ~np.isfinite(d["fun"])
+    n_par = d["x"].shape[1]
+    assert np.allclose(o["x"][bad][:, :n_par], d["x"][bad]) and np.all(o["nit"][bad] == 0)
+
+
+@pytest.mark.parametrize("path", [f for f in FILES if "gaussian_prior_te6" in f or "gaussian_rician_prior_te3" in f],
+                         ids=lambda p: os.path.basename(p)[7:-4])
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_lm_lane_solver_reaches_minimum(path, precision):
+    d = np.load(path)
+    mode = str(d["mode"])
+    cfg = sim.config(mode, bool(d["low_field"]), d["te"], prior=True, solver="lm", precision=precision)
+    o = sim.fit_rows(cfg, d["y"])
+    good = ~d["raised"] & np.isfinite(d["f_tight"]) & np.isfinite(o["fun"])
+    dt = np.abs(o["x"][good, 1] - d["x_tight"][good, 1])
+    assert np.mean(dt <= 1.0) >= (0.99 if mode == "gaussian" else 0.97)
+
+
+def test_residual_map_matches_reference():
+    """compute_residuals restated per lane (float64 prediction stored as float32, float32 residuals,
+    numpy's pairwise float32 row sum): evaluated on the reference's own parameters it must give the
+    reference's float32 residuals bit-for-bit, except where exp() rounds differently (<= 1e-3)."""
+    for path in FILES[::5]:
+        d = np.load(path)
+        cfg = sim.config(str(d["mode"]), bool(d["low_field"]), d["te"], prior=bool(d["prior"]), solver="lbfgsb")
+        rows = np.where(~d["raised"] & np.isfinite(d["res"]))[0]
+        x = d["x"][rows]
+        sg = x[:, 2] if x.shape[1] == 3 else np.zeros(len(rows))
+        res = sim.residuals(cfg, d["y"][rows], x[:, 0], x[:, 1], sg)
+        assert np.mean(res == d["res"][rows]) >= 0.9, path
+        assert np.max(np.abs(res - d["res"][rows])) <= 1e-3, path
