@@ -27,6 +27,12 @@ def load() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m fetal_t2mapping_amd.build` "
                 "(hipcc, gfx950).  fetal_t2mapping_amd has no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 and this package
+        # uses torch for device buffers, so torch is imported first and libt2fit_hip.so then binds
+        # to the runtime torch already loaded (same SONAME).  Loading ours first makes torch's
+        # later initialisation fail with "No HIP GPUs are available".
+        import torch  # noqa: F401
+
         lib = _abi.bind(C.CDLL(LIB_PATH))
         if lib.t2fit_abi_version() != _abi.ABI_VERSION:
             raise RuntimeError("libt2fit_hip.so ABI version does not match fetal_t2mapping_amd/_abi.py")
