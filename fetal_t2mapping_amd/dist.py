@@ -1,0 +1,93 @@
+"""Voxel-slab partition across the GPUs of one node + the final all-gather of the maps.
+
+The reference has no distributed code (its only parallelism is ``Pool(20).map`` over voxels,
+run_t2mapping.py:442-443).  Voxels are independent -- ``fit_voxel`` reads one row (:240) -- so the path
+shards by flat C-order voxel index with no exchange during the fit; north_star asks for one RCCL
+all-gather of the output maps at the end.  One process per GPU (``torch.distributed``, backend
+"nccl" = RCCL on ROCm; "gloo" on CPU for the tests of this module's host logic).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import numpy as np
+
+N_MAPS = 4  # t2, k, sigma, res (utils/t2map_utils.py:18-29)
+
+
+def slab_len(n_vox: int, world: int) -> int:
+    """Voxels per rank: ceil(N / G); the last slab is padded (mask 0) so all-gather counts are equal."""
+    return int(math.ceil(n_vox / world)) if n_vox else 0
+
+
+def slab_range(n_vox: int, rank: int, world: int) -> Tuple[int, int]:
+    """Half-open flat-index range ``[lo, hi)`` of rank ``rank``; equals Z-slabs when Z % world == 0."""
+    per = slab_len(n_vox, world)
+    lo = min(rank * per, n_vox)
+    return lo, min(lo + per, n_vox)
+
+
+def take_slab(echoes: np.ndarray, mask: Optional[np.ndarray], rank: int, world: int):
+    """Cut rank's padded slab out of a TE-major ``(nTE, N)`` stack (+ ``(N,)`` mask) on the host.
+
+    Returns ``(echoes_slab (nTE, per) f32, mask_slab (per,) u8)``; padding voxels have mask 0.
+    """
+    n_te, n = echoes.shape
+    per = slab_len(n, world)
+    lo, hi = slab_range(n, rank, world)
+    e = np.zeros((n_te, per), np.float32)
+    e[:, : hi - lo] = echoes[:, lo:hi]
+    m = np.zeros(per, np.uint8)
+    m[: hi - lo] = 1 if mask is None else (np.asarray(mask).reshape(-1)[lo:hi] != 0)
+    return e, m
+
+
+def gather_maps(packed_local, n_vox: int, group=None):
+    """All-gather the per-rank packed maps ``[N_MAPS, per]`` into ``[N_MAPS, n_vox]`` on every rank.
+
+    ``packed_local``: torch tensor (CUDA with RCCL, CPU with gloo).  One collective moves all maps.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    per = packed_local.shape[1]
+    assert packed_local.shape[0] == N_MAPS and per == slab_len(n_vox, world)
+    packed_local = packed_local.contiguous()
+    gathered = torch.empty((world, N_MAPS, per), dtype=packed_local.dtype, device=packed_local.device)
+    dist.all_gather_into_tensor(gathered.view(-1), packed_local.view(-1), group=group)
+    # [world, N_MAPS, per] -> [N_MAPS, world*per] -> trim the padding of the last slab
+    return gathered.permute(1, 0, 2).reshape(N_MAPS, world * per)[:, :n_vox]
+
+
+def fit_volume_sharded(echoes: np.ndarray, mask: Optional[np.ndarray], TEeffs, fit, fit_params, prior=True,
+                       norm=False, *, solver="lbfgsb", precision="f64", group=None):
+    """Every rank passes the same host ``(nTE, Z, Y, X)`` stack; each fits its slab on its own GPU and
+    all ranks return the complete ``T2Maps`` (torch CUDA tensors shaped ``(Z, Y, X)``)."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+
+    from . import _abi
+    from ._lib import check, require_gpu
+    from .t2map import T2Maps, make_config
+
+    lib = require_gpu()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    spatial = echoes.shape[1:]
+    n = int(np.prod(spatial))
+    e, m = take_slab(np.ascontiguousarray(echoes, np.float32).reshape(echoes.shape[0], n), mask, rank, world)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    e_d, m_d = torch.from_numpy(e).to(dev), torch.from_numpy(m).to(dev)
+    per = e.shape[1]
+    packed = torch.empty((N_MAPS, per), dtype=torch.float32, device=dev)
+    cfg = make_config(fit, fit_params, TEeffs, prior, norm, solver, precision)
+    maps = _abi.T2FitMaps()
+    maps.t2, maps.k, maps.sigma, maps.res = (packed[j].data_ptr() for j in range(N_MAPS))
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.t2fit_volume_dev(C.byref(cfg), e_d.data_ptr(), _abi.LAYOUT_TE_MAJOR, m_d.data_ptr(), per,
+                               C.byref(maps), C.c_void_p(st)))
+    full = gather_maps(packed, n, group)
+    return T2Maps(*(full[j].reshape(spatial) for j in range(N_MAPS)))

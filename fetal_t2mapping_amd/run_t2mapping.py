@@ -1,0 +1,237 @@
+"""CLI and volume driver: the reference's ``run_t2mapping.py`` surface on the MI355X fit.
+
+    python -m fetal_t2mapping_amd.run_t2mapping --path /data/qMRI --csv 2024083017_17510000.csv \
+        --in_vivo --gaussian --lf --sim 1 [--TEs 114 202 299] [--no_prior] [--solver lbfgsb|lm]
+
+Same flags, metadata CSVs, input/output file names and maps as the reference
+(run_t2mapping.py:483-576, utils/metadata_utils.py, utils/qmri_utils.py:13-33,
+utils/t2map_utils.py:18-59); the voxel loop (:411-461) is one call into the HIP library.  NIfTI I/O
+stays SimpleITK on the host, as in the reference.  Not carried over: the matplotlib convergence plots
+(:465-468, they need per-iteration Python lists for 50 random voxels) and the hard-coded ``prj-00X``
+CSV lists of the authors' lab (utils/metadata_utils.py:19-85) -- pass the CSV names instead.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import t2map
+
+# derivative directory names (utils/metadata_utils.py:4-17)
+recon_dirname = "recon_1mm"
+mask_dirname = "recon_1mm_mask"
+phantom_labels_dirname = "recon_1mm_label"
+t2map_dirname = recon_dirname + "_t2map"
+
+
+def _sitk():
+    try:
+        import SimpleITK as sitk
+    except ImportError as e:  # the fit does not need it; only the file edge does
+        raise RuntimeError("SimpleITK is required for NIfTI I/O (pip install SimpleITK)") from e
+    return sitk
+
+
+# ---- metadata / paths --------------------------------------------------------------------------
+def mk_bids_dir(bids_dir, *dirs):
+    """utils/dcm_utils.py:189-195."""
+    path = bids_dir
+    for d in dirs:
+        path = os.path.join(path, d)
+        if not os.path.exists(path):
+            os.mkdir(path)
+
+
+def get_img_path(bids_path, acq, type: str = "anat"):
+    """utils/qmri_utils.py:13-33 (same file names, including the width-3 TE field)."""
+    if type == "anat":
+        dirs = [acq["prj"], acq["sub"], acq["ses"], "anat"]
+        name = "_".join([acq["sub"], acq["ses"], acq["run"] + "_T2w.nii.gz"])
+    elif "t2map" in type:
+        dirs = [acq["prj"], "derivatives", type, acq["sub"], acq["ses"], "anat"]
+        name = "_".join([acq["sub"], acq["ses"], type + ".nii.gz"])
+    elif "recon" in type:
+        dirs = [acq["prj"], "derivatives", type, acq["sub"], acq["ses"], "anat"]
+        if acq["CoilString"] == "Simulation":
+            name = "_".join([acq["sub"], acq["ses"], f"t2-{int(acq['T2']):3}", f"te-{int(acq['EchoTime']):3}",
+                             type + ".nii.gz"])
+        else:
+            name = "_".join([acq["sub"], acq["ses"], f"te-{int(acq['EchoTime'] * 1000):3}", type + ".nii.gz"])
+    else:
+        dirs = [acq["prj"], "derivatives", type, acq["sub"], acq["ses"], "anat"]
+        name = "_".join([acq["sub"], acq["ses"], acq["run"], "T2w", type + ".nii.gz"])
+    mk_bids_dir(bids_path, *dirs)
+    return os.path.join(os.path.join(bids_path, *dirs), name)
+
+
+def set_metadata(csv_path, csvs, low_field):
+    """utils/metadata_utils.py:92-125: concatenate the session log CSVs into one DataFrame."""
+    import pandas as pd
+
+    if ".csv" not in csvs[0].lower():
+        print(f"Error: {csvs} is not a valid metadata log file (the reference's hard-coded prj-00X file "
+              "lists are not carried over; pass the CSV names).")
+        raise SystemExit(1)
+    return pd.concat([pd.read_csv(os.path.join(csv_path, c)) for c in csvs])
+
+
+def set_phantom_gt(low_field):
+    """run_t2mapping.py:14-27 (NMR ground-truth T2 of the NIST phantom vials); returns (gt, id)."""
+    if low_field:
+        gt = [594, 416, 284, 221, 167, 122, 80, 53, 41]
+        ids = ["T2-3", "T2-4", "T2-5", "T2-6", "T2-7", "T2-8", "T2-9", "T2-10", "T2-11"]
+    else:
+        gt = [1044, 624, 428, 258, 186, 137, 90, 63, 44, 27, 19, 15, 10, 8]
+        ids = [f"T2-{i}" for i in range(1, 15)]
+    return gt, ids
+
+
+# ---- outputs -----------------------------------------------------------------------------------
+def save_nifti_maps(t2_map, k_map, sigma_map, res_map, dirname, recon_img, bids_path, acq, sim, analysis):
+    """utils/t2map_utils.py:18-29."""
+    sitk = _sitk()
+    for arr, tag in zip([t2_map, k_map, sigma_map, res_map], ["t2", "k", "sigma", "res"]):
+        img = sitk.GetImageFromArray(arr)
+        img.SetSpacing(recon_img.GetSpacing())
+        img.SetOrigin(recon_img.GetOrigin())
+        img.SetDirection(recon_img.GetDirection())
+        path = get_img_path(bids_path, acq.iloc[0], dirname)
+        path = path.replace("t2map.nii.gz", "sim-" + str(sim) + f"_{tag}map_ada-{analysis}.nii.gz")
+        sitk.WriteImage(img, path)
+    print(f"T2 map saved as nifti file in {dirname}")
+
+
+def save_phantom_csv(t2_map, k_map, sigma_map, label, id, gt, bids_path, acq, dirname, sim, analysis):
+    """utils/t2map_utils.py:30-59: nanmean / nanstd of each map per vial label."""
+    import pandas as pd
+
+    n_roi = len(gt)
+    cols = {name: np.zeros(n_roi) for name in ("meanT2", "stdT2", "meanK", "stdK", "meanC", "stdC")}
+    for i in range(n_roi):
+        sel = label == i + 1
+        for arr, m, s in ((t2_map, "meanT2", "stdT2"), (k_map, "meanK", "stdK"), (sigma_map, "meanC", "stdC")):
+            cols[m][i] = np.nanmean(arr[sel])
+            cols[s][i] = np.nanstd(arr[sel])
+    df = pd.DataFrame({"id": id, "trueT2": gt, **cols})
+    path = get_img_path(bids_path, acq.iloc[0], dirname).replace("t2map.nii.gz", f"sim-{sim}_ROI_data_ada-{analysis}.csv")
+    df.to_csv(path, index=False)
+
+
+# ---- driver ------------------------------------------------------------------------------------
+def _fit_subject(vols, masks, keep, te_eff, fit, fit_params, prior, norm, solver, precision, device):
+    """One (sub, ses): union mask + flat indices on the device (bit-identical to
+    run_t2mapping.py:383-384,412,421), fit, maps back to the host as (Z,Y,X) float32."""
+    import torch
+
+    echoes, mask, _ = t2map.stack_mask_flatten(vols, masks, device=device)
+    if keep is not None:
+        mask = mask & keep
+    shape = mask.shape
+    mask_d = torch.from_numpy(mask.astype(np.uint8).reshape(-1)).to(echoes.device)
+    maps = t2map.fit_volume(echoes.reshape((len(vols),) + shape), mask_d, te_eff, fit, fit_params, prior=prior,
+                            norm=norm, solver=solver, precision=precision, extras=True)
+    torch.cuda.synchronize()
+    out = tuple(getattr(maps, n).cpu().numpy() for n in ("t2", "k", "sigma", "res"))
+    return mask, out, maps.status.cpu().numpy()
+
+
+def process_t2maps(metadata, bids_path, TEs, fit, fit_params, phantom, low_field, prior, fast, norm, sim,
+                   solver="lbfgsb", precision="f64", device=0):
+    """run_t2mapping.py:333-479 with the voxel loop on the GPU."""
+    sitk = _sitk()
+    tes_s = [x / 1000 for x in TEs]
+    metadata = metadata[metadata["EchoTime"].isin(tes_s)]
+    for prj, prj_md in metadata.groupby("prj"):
+        for (sub, ses), sub_md in prj_md.groupby(["sub", "ses"]):
+            vols, masks, te_eff = [], [], []
+            for echotime, acq in sub_md.groupby("EchoTime"):
+                te_eff.append(echotime * 1000)
+                recon_path = get_img_path(bids_path, acq.iloc[0], recon_dirname).replace(" ", "")
+                mask_path = get_img_path(bids_path, acq.iloc[0], mask_dirname).replace(" ", "")
+                if phantom:
+                    label_path = get_img_path(bids_path, acq.iloc[0], phantom_labels_dirname).replace(" ", "")
+                recon_img = sitk.ReadImage(recon_path)
+                masks.append(sitk.GetArrayFromImage(sitk.ReadImage(mask_path)))
+                vols.append(sitk.GetArrayFromImage(recon_img))
+            label = sitk.GetArrayFromImage(sitk.ReadImage(label_path)) if phantom else None
+            te_eff = np.array(te_eff)
+            if not np.array_equal(te_eff, TEs):
+                print(f"Warning: one or more TEs selected to fit is missing for {sub}_{ses}. T2 fit is skipped.")
+                continue
+            keep = (label != 0) if (phantom and fast) else None  # :394-400
+            print(f"T2 Mapping: {prj}_{sub}_{ses}")
+            print(f"TEeffs: {te_eff}")
+            print(f"Fitting using {fit} model ... ")
+            t0 = time.time()
+            mask, (t2_map, k_map, sigma_map, res_map), status = _fit_subject(
+                vols, masks, keep, te_eff, fit, fit_params, prior, norm, solver, precision, device)
+            print(f"Dimensions of the t2w images: {mask.shape + (te_eff.size,)} (z,y,x,necho)")
+            print(f"Mask Dimension: {mask.shape} -  Number of voxels inside mask: {int(np.sum(mask))}")
+            if np.any(status == 4):  # scipy raises here and the reference's pool.map aborts the run
+                raise ValueError("LBFGSB - one of the lower bounds is greater than an upper bound.")
+            n_fail = int(np.sum((status != 1) & (status != 0)))
+            if n_fail:
+                print(f"FAIL : Optimization failed for {n_fail} voxels")
+            print(f"... done. Time to fit: {round(time.time() - t0, 4)} sec")
+            save_nifti_maps(t2_map, k_map, sigma_map, res_map, t2map_dirname, recon_img, bids_path, acq, sim, fit)
+            if phantom:
+                # the reference unpacks (gt, id) as id, gt (run_t2mapping.py:27 vs :478), which swaps the
+                # CSV's `id` and `trueT2` columns; kept so the output file is identical
+                id_, gt_ = set_phantom_gt(low_field)
+                save_phantom_csv(t2_map, k_map, sigma_map, label, id_, gt_, bids_path, acq, t2map_dirname, sim, fit)
+
+
+def parse_arguments(argv=None):
+    """run_t2mapping.py:483-518 plus --solver / --precision / --device."""
+    p = argparse.ArgumentParser(description="T2 Mapping Parser (MI355X)", formatter_class=argparse.RawTextHelpFormatter)
+    p.add_argument("--path", type=str, required=True, help="Path to general directory ../qMRI/")
+    p.add_argument("--csv", type=str, nargs="+", required=True, help="Name of one or more metadata CSV log files")
+    g = p.add_mutually_exclusive_group(required=True)
+    g.add_argument("--in_vivo", action="store_true", help="Process in vivo data")
+    g.add_argument("--in_vitro", action="store_true", help="Process NIST Phantom data and generate full map")
+    g.add_argument("--in_vitro_fast", action="store_true", help="Process NIST Phantom data only at ROI")
+    g = p.add_mutually_exclusive_group(required=True)
+    g.add_argument("--gaussian", action="store_true", help="T2 fit under gaussian noise assumption")
+    g.add_argument("--gaussian_rician", action="store_true", help="T2 fit under gaussian-rician noise assumption")
+    g.add_argument("--rician", action="store_true", help="T2 fit under rician noise assumption")
+    g = p.add_mutually_exclusive_group(required=True)
+    g.add_argument("--lf", action="store_true", help="Process low-field 0.55 T data")
+    g.add_argument("--hf", action="store_true", help="Process high-field 1.5 T data")
+    p.add_argument("--sim", type=str, required=True, help="T2 fitting ID (can be a description or a simple int)")
+    p.add_argument("--TEs", nargs="+", type=int, help="List of TEs to fit\n   default low-field: [114,202,299]\n"
+                                                      "   default high-field: [115,202,299]")
+    p.add_argument("--no_prior", action="store_true", default=False, help="If set, will not restrict M0 bounds")
+    p.add_argument("--norm", action="store_true", default=False, help="If set, will normalize T2w data")
+    p.add_argument("--solver", choices=["lbfgsb", "lm"], default="lbfgsb",
+                   help="lbfgsb: the reference's solver and stop rules (default); lm: converged bounded LM")
+    p.add_argument("--precision", choices=["f64", "f32"], default="f64", help="arithmetic of the lm solver")
+    p.add_argument("--device", type=int, default=0)
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    """run_t2mapping.py:522-576."""
+    args = parse_arguments(argv)
+    if not os.path.exists(args.path):
+        print(f"Error: The specified path does not exist: {args.path}")
+        raise SystemExit(1)
+    bids_path = os.path.join(args.path, "projects/")
+    csv_path = os.path.join(args.path, "dicom/logs/")
+    low_field = bool(args.lf)
+    TEs = args.TEs if args.TEs is not None else ([114, 202, 299] if args.lf else [115, 202, 299])
+    phantom = bool(args.in_vitro or args.in_vitro_fast)
+    fast = bool(args.in_vitro_fast)
+    if args.norm:
+        print("Warning: Fitting using normalization is not optimal !")
+    fit, fit_params = t2map.set_fit_params(args)
+    metadata = set_metadata(csv_path, args.csv, low_field)
+    process_t2maps(metadata, bids_path, TEs, fit, fit_params, phantom, low_field, not args.no_prior, fast,
+                   bool(args.norm), args.sim, solver=args.solver, precision=args.precision, device=args.device)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

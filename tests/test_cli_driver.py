@@ -1,0 +1,89 @@
+"""Host logic of the CLI / volume driver (run_t2mapping.py mirror) on CPU: flags, metadata filter,
+input and output file names, geometry copy, map scatter.  The GPU fit is replaced by the oracle here
+(checker standing in for the kernel); tests/test_gpu_parity.py runs the same driver on the device."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import fake_sitk
+from conftest import GOLDEN
+from oracle import t2fit_oracle as O
+
+
+def _subject(tmp_path, d):
+    from fetal_t2mapping_amd import run_t2mapping as R
+
+    bids = str(tmp_path / "projects") + "/"
+    os.makedirs(os.path.join(bids, "prj-900"))
+    rows = []
+    for i, t in enumerate(d["te"]):
+        acq = {"prj": "prj-900", "sub": "sub-001", "ses": "ses-01", "run": f"run-{i + 1:02d}", "EchoTime": t / 1000.0,
+               "CoilString": "HeadNeck"}
+        rows.append(acq)
+        np.save(R.get_img_path(bids, acq, R.recon_dirname).replace(" ", "") + ".npy", d["echoes"][i])
+        np.save(R.get_img_path(bids, acq, R.mask_dirname).replace(" ", "") + ".npy", d["masks"][i])
+    return bids, pd.DataFrame(rows)
+
+
+def _oracle_fit_subject(vols, masks, keep, te_eff, fit, fit_params, prior, norm, solver, precision, device):
+    data, mask, idx = O.stack_mask_flatten(vols, masks)
+    if keep is not None:
+        mask = mask & keep
+        idx = np.flatnonzero(mask.reshape(-1))
+    r = O.fit_volume(data, idx, te_eff, fit, O.fit_table(fit, True), prior=prior, norm=norm)
+    st = np.zeros(data.shape[0], np.uint8)
+    st[idx] = np.where(r.success, 1, 2)
+    sh = mask.shape
+    return mask, (r.t2.reshape(sh), r.k.reshape(sh), r.sigma.reshape(sh), r.res.reshape(sh)), st
+
+
+def test_process_t2maps_plumbing_matches_reference_run(tmp_path, monkeypatch):
+    from fetal_t2mapping_amd import run_t2mapping as R
+
+    sitk = fake_sitk.install()
+    d = np.load(os.path.join(GOLDEN, "volume_lf_gaussian_noprior.npz"))
+    bids, md = _subject(tmp_path, d)
+    monkeypatch.setattr(R, "_fit_subject", _oracle_fit_subject)
+    args = R.parse_arguments(["--path", str(tmp_path), "--csv", "x.csv", "--in_vivo", "--gaussian", "--lf", "--sim", "g1",
+                              "--no_prior"])
+    fit, fit_params = R.t2map.set_fit_params(args)
+    R.process_t2maps(md, bids, [int(t) for t in d["te"]], fit, fit_params, False, True, False, False, False, "g1")
+    names = sorted(os.path.relpath(p, bids) for p in sitk.written)
+    assert names == [str(s) for s in d["written"]]
+    for path, img in sitk.written.items():
+        key = path.split("_sim-g1_")[1].split("map_")[0]
+        assert np.array_equal(img.arr, d[key]), key  # oracle == reference, so the plumbing must be exact
+        assert img.GetSpacing() == tuple(d["spacing"]) and img.GetOrigin() == tuple(d["origin"])
+
+
+def test_cli_flags_and_tables():
+    from fetal_t2mapping_amd import run_t2mapping as R
+
+    with pytest.raises(SystemExit):
+        R.parse_arguments(["--path", "p", "--csv", "c.csv", "--in_vivo", "--gaussian", "--rician", "--lf", "--sim", "1"])
+    with pytest.raises(SystemExit):
+        R.parse_arguments(["--path", "p", "--csv", "c.csv", "--gaussian", "--lf", "--sim", "1"])
+    a = R.parse_arguments(["--path", "p", "--csv", "a.csv", "b.csv", "--in_vitro_fast", "--rician", "--hf", "--sim", "s"])
+    fit, fp = R.t2map.set_fit_params(a)
+    assert fit == "rician" and fp == O.fit_table("rician", False)
+    for mode in O.MODES:
+        for lf in (True, False):
+            assert R.t2map.fit_table(mode, lf) == O.fit_table(mode, lf)
+    a.norm = True
+    with pytest.raises(SystemExit):  # run_t2mapping.py:107-109
+        R.t2map.set_fit_params(a)
+    assert R.set_phantom_gt(True)[0][0] == 594 and len(R.set_phantom_gt(False)[0]) == 14
+
+
+def test_missing_te_is_skipped(tmp_path, monkeypatch, capsys):
+    from fetal_t2mapping_amd import run_t2mapping as R
+
+    sitk = fake_sitk.install()
+    d = np.load(os.path.join(GOLDEN, "volume_lf_gaussian_noprior.npz"))
+    bids, md = _subject(tmp_path, d)
+    monkeypatch.setattr(R, "_fit_subject", _oracle_fit_subject)
+    R.process_t2maps(md, bids, [114, 202, 250], "gaussian", O.fit_table("gaussian", True), False, True, True, False,
+                     False, "s")
+    assert "T2 fit is skipped" in capsys.readouterr().out and not sitk.written

@@ -1,0 +1,71 @@
+"""N > 1 path on CPU: slab partition + all-gather of the packed maps with gloo, world_size 2 and 3.
+
+The fit itself needs the GPU, so each rank fills its packed slab with a deterministic per-voxel
+function (standing in for the kernel, whose per-voxel result does not depend on the partition);
+what is tested is that partition + padding + one all_gather_into_tensor reproduce the whole volume
+bit-for-bit on every rank, including ragged sizes."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from fetal_t2mapping_amd import dist as t2dist
+
+
+def _fake_fit(echoes_slab, mask_slab):
+    """Per-voxel stand-in for the kernel: depends only on that voxel's samples and mask."""
+    e = echoes_slab.astype(np.float64)
+    t2 = np.where(mask_slab != 0, e.sum(axis=0) * 0.5, 0.0)
+    k = np.where(mask_slab != 0, e[0] * 2.0 + 1.0, 0.0)
+    sg = np.where(mask_slab != 0, e[-1] - e[0], 0.0)
+    res = np.where(mask_slab != 0, e.mean(axis=0), 0.0)
+    return np.stack([t2, k, sg, res]).astype(np.float32)
+
+
+def _worker(rank, world, port, n_vox, n_te, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(5)
+    echoes = rng.normal(size=(n_te, n_vox)).astype(np.float32)
+    mask = (rng.random(n_vox) < 0.6).astype(np.uint8)
+    e, m = t2dist.take_slab(echoes, mask, rank, world)
+    assert e.shape == (n_te, t2dist.slab_len(n_vox, world))
+    packed = torch.from_numpy(_fake_fit(e, m))
+    full = t2dist.gather_maps(packed, n_vox).numpy()
+    whole = _fake_fit(echoes, mask)
+    ok = np.array_equal(full, whole)
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,n_vox", [(2, 1000), (2, 1001), (3, 10), (2, 1)])
+def test_slab_partition_and_allgather(world, n_vox):
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n_vox, 4, out), nprocs=world, join=True)
+    assert all(out[r] for r in range(world)) and len(out) == world
+
+
+def test_slab_ranges_cover_the_volume():
+    for n in (0, 1, 7, 8, 9, 360 * 512 * 512):
+        for g in (1, 2, 4, 8):
+            per = t2dist.slab_len(n, g)
+            spans = [t2dist.slab_range(n, r, g) for r in range(g)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert all(hi - lo <= per for lo, hi in spans)
+    # cfg4: 360 slices over 8 GPUs are whole Z-slabs of 45 slices
+    assert t2dist.slab_range(360 * 512 * 512, 3, 8) == (3 * 45 * 512 * 512, 4 * 45 * 512 * 512)

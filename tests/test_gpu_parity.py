@@ -268,3 +268,47 @@ def test_lbfgsb_size_independent_properties(t2):
                        layout="voxel_major", extras=True)
     for name in ("t2", "k", "sigma", "res", "nit", "status"):
         assert np.array_equal(getattr(whole, name), getattr(vm, name), equal_nan=True)
+
+
+def test_cli_driver_on_device(t2, tmp_path):
+    """The run_t2mapping.py mirror end to end on the GPU with npy-backed image I/O: same output files
+    as the reference's run, maps within tolerance, phantom CSV written for --in_vitro."""
+    import pandas as pd
+
+    import fake_sitk
+    from fetal_t2mapping_amd import run_t2mapping as R
+
+    sitk = fake_sitk.install()
+    d = np.load(os.path.join(GOLDEN, "volume_lf_gaussian_noprior.npz"))
+    bids = str(tmp_path / "projects") + "/"
+    os.makedirs(os.path.join(bids, "prj-900"))
+    rows = []
+    label = np.zeros(d["echoes"].shape[1:], np.int16)
+    label[2:4, 4:8, 4:8] = 1
+    label[2:4, 4:8, 8:11] = 2
+    for i, t in enumerate(d["te"]):
+        acq = {"prj": "prj-900", "sub": "sub-001", "ses": "ses-01", "run": f"run-{i + 1:02d}", "EchoTime": t / 1000.0,
+               "CoilString": "HeadNeck"}
+        rows.append(acq)
+        np.save(R.get_img_path(bids, acq, R.recon_dirname).replace(" ", "") + ".npy", d["echoes"][i])
+        np.save(R.get_img_path(bids, acq, R.mask_dirname).replace(" ", "") + ".npy", d["masks"][i])
+        np.save(R.get_img_path(bids, acq, R.phantom_labels_dirname).replace(" ", "") + ".npy", label)
+    md = pd.DataFrame(rows)
+    table = t2.fit_table("gaussian", True)
+    R.process_t2maps(md, bids, [int(t) for t in d["te"]], "gaussian", table, False, True, False, False, False, "g1")
+    assert sorted(os.path.relpath(p, bids) for p in sitk.written) == [str(s) for s in d["written"]]
+    mask = d["masks"].sum(axis=0) > 0
+    for path, img in sitk.written.items():
+        key = path.split("_sim-g1_")[1].split("map_")[0]
+        assert img.arr.shape == d[key].shape and img.arr.dtype == np.float32
+        assert np.array_equal(img.arr[~mask], d[key][~mask])
+        if key == "t2":
+            assert np.mean(np.abs(img.arr[mask] - d[key][mask]) <= T2_TOL_MS) >= 0.95
+    # --in_vitro_fast: only labelled voxels are fitted, ROI csv appears
+    sitk.written.clear()
+    R.process_t2maps(md, bids, [int(t) for t in d["te"]], "gaussian", t2.fit_table("gaussian", True), True, True, True,
+                     True, False, "p1")
+    t2img = [img for p, img in sitk.written.items() if "_t2map_" in p][0]
+    assert np.all(t2img.arr[label == 0] == 0)
+    csv = [f for f in os.listdir(os.path.dirname(list(sitk.written)[0])) if f.endswith(".csv")]
+    assert csv == ["sub-001_ses-01_recon_1mm_sim-p1_ROI_data_ada-gaussian.csv"]
