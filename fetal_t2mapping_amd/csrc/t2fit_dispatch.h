@@ -63,6 +63,7 @@ T2_HD void fit_lane_t(const LaneParams& P, EchoView y, LaneResult& r) {
   double lb[3], ub[3];
   const bool feasible = lane_bounds(P, y[0], lb, ub);
   r.nit = 0;
+  r.nfev = 0;
   r.fun = NAN;
   if (!feasible) {
     // scipy raises "one of the lower bounds is greater than an upper bound" (whole volume aborts)

@@ -12,6 +12,8 @@
 // The fit itself is ALU work (exp/sqrt/fma, fp32 or fp64); no MFMA: nothing here is a contraction.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -25,6 +27,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kLdsStride = kBlock + 1;
+int g_persistent_blocks = 2048;  // grid of the persistent kernel (T2FIT_PERSISTENT_BLOCKS overrides)
 
 thread_local std::string g_err;
 thread_local bool g_timing = false;
@@ -75,6 +78,29 @@ __device__ __forceinline__ void stage_echoes(float* lds, const float* __restrict
   }
 }
 
+__device__ __forceinline__ void store_masked(const DevMaps& m, int64_t v) {
+  // zeros outside the mask (run_t2mapping.py:415-418)
+  m.t2[v] = 0.0f; m.k[v] = 0.0f; m.sigma[v] = 0.0f; m.res[v] = 0.0f;
+  if (m.r2) m.r2[v] = 0.0f;
+  if (m.fun) m.fun[v] = 0.0f;
+  if (m.nit) m.nit[v] = 0;
+  if (m.status) m.status[v] = T2FIT_ST_MASKED;
+  if (m.xd) { m.xd[3 * v] = 0.0; m.xd[3 * v + 1] = 0.0; m.xd[3 * v + 2] = 0.0; }
+  if (m.fund) m.fund[v] = 0.0;
+}
+
+__device__ __forceinline__ void store_result(const DevMaps& m, int64_t v, const LaneOutputs& o, const LaneResult& r) {
+  m.t2[v] = o.t2; m.k[v] = o.k; m.sigma[v] = o.sigma; m.res[v] = o.res;
+  if (m.r2) m.r2[v] = o.r2;
+  if (m.fun) m.fun[v] = o.fun;
+  if (m.nit) m.nit[v] = o.nit;
+  if (m.status) m.status[v] = o.status;
+  if (m.xd) { m.xd[3 * v] = r.x[0]; m.xd[3 * v + 1] = r.x[1]; m.xd[3 * v + 2] = r.x[2]; }
+  if (m.fund) m.fund[v] = r.fun;
+}
+
+// One lane per voxel, one voxel per lane: used for the LM solver and as the fallback of the
+// persistent kernel below.
 template <int SOLVER, int PREC, int MODEL>
 __global__ __launch_bounds__(kBlock) void fit_volume_kernel(const LaneParams P, const float* __restrict__ echoes,
                                                             int layout, const uint8_t* __restrict__ mask,
@@ -87,14 +113,8 @@ __global__ __launch_bounds__(kBlock) void fit_volume_kernel(const LaneParams P, 
   const bool active = in_range && (mask == nullptr || mask[v] != 0);
   stage_echoes(lds, echoes, layout, P.n_te, n_vox, base, active);
   if (!in_range) return;
-  if (!active) {  // zeros outside the mask (run_t2mapping.py:415-418)
-    m.t2[v] = 0.0f; m.k[v] = 0.0f; m.sigma[v] = 0.0f; m.res[v] = 0.0f;
-    if (m.r2) m.r2[v] = 0.0f;
-    if (m.fun) m.fun[v] = 0.0f;
-    if (m.nit) m.nit[v] = 0;
-    if (m.status) m.status[v] = T2FIT_ST_MASKED;
-    if (m.xd) { m.xd[3 * v] = 0.0; m.xd[3 * v + 1] = 0.0; m.xd[3 * v + 2] = 0.0; }
-    if (m.fund) m.fund[v] = 0.0;
+  if (!active) {
+    store_masked(m, v);
     return;
   }
   const EchoView y{lds + lane, kLdsStride};
@@ -102,13 +122,125 @@ __global__ __launch_bounds__(kBlock) void fit_volume_kernel(const LaneParams P, 
   fit_lane_t<SOLVER, PREC, MODEL>(P, y, r);
   LaneOutputs o;
   lane_epilogue(P, y, r, o, m.r2 != nullptr);
-  m.t2[v] = o.t2; m.k[v] = o.k; m.sigma[v] = o.sigma; m.res[v] = o.res;
-  if (m.r2) m.r2[v] = o.r2;
-  if (m.fun) m.fun[v] = o.fun;
-  if (m.nit) m.nit[v] = o.nit;
-  if (m.status) m.status[v] = o.status;
-  if (m.xd) { m.xd[3 * v] = r.x[0]; m.xd[3 * v + 1] = r.x[1]; m.xd[3 * v + 2] = r.x[2]; }
-  if (m.fund) m.fund[v] = r.fun;
+  store_result(m, v, o, r);
+}
+
+// Persistent form of the reference-trajectory fit.  The number of objective evaluations per voxel
+// varies 4..200 (line searches), so with one voxel per lane a wave waits for its slowest voxel
+// (measured lane efficiency 0.53).  Here a wave keeps all 64 lanes busy instead: waves pull chunks
+// of kChunk consecutive voxels from a global atomic counter, zero-fill the masked-out ones, queue
+// the active ones in LDS, and every lane that finishes a voxel pops the next one.  The loop body is
+// one objective+gradient evaluation (uniform, expensive) followed by the lane's solver advance
+// (divergent, cheap); the wave leaves when a __ballot shows no lane has work and the queue is dry.
+constexpr int kChunk = 256;
+constexpr int kQueueCap = 64 + kChunk;
+
+template <int MODEL>
+__global__ __launch_bounds__(kBlock) void fit_lbfgsb_persistent_kernel(const LaneParams P,
+                                                                       const float* __restrict__ echoes, int layout,
+                                                                       const uint8_t* __restrict__ mask, int64_t n_vox,
+                                                                       DevMaps m, unsigned long long* next_chunk) {
+  extern __shared__ float lds[];
+  constexpr int NP = MODEL == T2FIT_MODEL_GAUSSIAN ? 2 : 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* col = lds + threadIdx.x;
+  // LDS: [n_te][257] float sample columns | [2*M*N][256] double correction pairs | 4 queues
+  double* hist = reinterpret_cast<double*>(lds + ((P.n_te * kLdsStride + 1) & ~1)) + threadIdx.x;
+  uint32_t* queue = reinterpret_cast<uint32_t*>(hist - threadIdx.x + 2 * Lbfgsb<MODEL>::M * NP * kBlock) + wave * kQueueCap;
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const EchoView y{col, kLdsStride};
+  int q_head = 0, q_count = 0;
+  bool chunks_left = true;
+  bool busy = false;
+  int64_t v = 0;
+  Lbfgsb<MODEL> s;
+  ObjCtx c;
+  c.P = &P;
+  c.y = y;
+  c.norm = P.norm != 0;
+  c.ymax = 1.0f;
+  for (;;) {
+    const unsigned long long need = __ballot(!busy);
+    if (need) {
+      const int n_need = __popcll(need);
+      while (q_count < n_need && chunks_left) {
+        unsigned long long cidx = 0;
+        if (lane == 0) cidx = atomicAdd(next_chunk, 1ull);
+        cidx = __shfl(cidx, 0, 64);
+        const int64_t base = (int64_t)cidx * kChunk;
+        if (base >= n_vox) { chunks_left = false; break; }
+        if (q_head != 0) {  // fewer than 64 entries are left: move them to the front
+          uint32_t tmp = 0;
+          if (lane < q_count) tmp = queue[q_head + lane];
+          if (lane < q_count) queue[lane] = tmp;
+          q_head = 0;
+        }
+#pragma unroll
+        for (int q = 0; q < kChunk / 64; ++q) {
+          const int64_t vv = base + q * 64 + lane;
+          const bool in = vv < n_vox;
+          const bool act = in && (mask == nullptr || mask[vv] != 0);
+          if (in && !act) store_masked(m, vv);
+          const unsigned long long b = __ballot(act);
+          if (act) queue[q_count + __popcll(b & lt_mask)] = (uint32_t)vv;
+          q_count += __popcll(b);
+        }
+      }
+      bool fresh = false;
+      if (!busy) {
+        const int rank = __popcll(need & lt_mask);
+        if (rank < q_count) {
+          v = (int64_t)queue[q_head + rank];
+          busy = true;
+          fresh = true;
+        }
+      }
+      const int taken = n_need < q_count ? n_need : q_count;
+      q_head += taken;
+      q_count -= taken;
+      if (fresh) {
+        // this lane's samples into its LDS column
+        if (layout == T2FIT_LAYOUT_TE_MAJOR) {
+          for (int i = 0; i < P.n_te; ++i) col[i * kLdsStride] = echoes[(int64_t)i * n_vox + v];
+        } else {
+          for (int i = 0; i < P.n_te; ++i) col[i * kLdsStride] = echoes[v * P.n_te + i];
+        }
+        bool finite;
+        const ObjCtx cc = make_ctx(P, y, finite);
+        c.ymax = cc.ymax;
+        double lb[3], ub[3];
+        const bool feasible = lane_bounds(P, y[0], lb, ub);
+        if (!feasible || !finite) {  // nothing to iterate on (fit_lane_t documents both cases)
+          LaneResult r;
+          r.nit = 0; r.nfev = 0; r.fun = NAN;
+          for (int j = 0; j < 3; ++j)
+            r.x[j] = !feasible ? (j < NP ? NAN : 0.0) : (j < NP ? t2_clip(P.x0[j], lb[j], ub[j]) : 0.0);
+          r.status = !feasible ? T2FIT_ST_INFEASIBLE : T2FIT_ST_NONFINITE;
+          LaneOutputs o;
+          lane_epilogue(P, y, r, o, m.r2 != nullptr);
+          store_result(m, v, o, r);
+          busy = false;
+        } else {
+          s.init(P, lb, ub, hist, kBlock);
+        }
+      }
+    }
+    if (__ballot(busy) == 0ull) {
+      if (!chunks_left && q_count == 0) break;
+      continue;
+    }
+    if (busy) {
+      s.eval(c);
+      if (s.advance(c)) {
+        LaneResult r;
+        s.result(r);
+        LaneOutputs o;
+        lane_epilogue(P, y, r, o, m.r2 != nullptr);
+        store_result(m, v, o, r);
+        busy = false;
+      }
+    }
+  }
 }
 
 // Residual map only (utils/t2map_utils.py:62-89) from float32 maps already on the device.
@@ -236,12 +368,20 @@ FitKernel pick_kernel(const t2fit_config& c) {
                ? fit_volume_kernel<T2FIT_SOLVER_LM, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN>
                : fit_volume_kernel<T2FIT_SOLVER_LM, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN_RICIAN>;
   }
-  switch (c.model) {
-    case T2FIT_MODEL_GAUSSIAN: return fit_volume_kernel<T2FIT_SOLVER_LBFGSB, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN>;
-    case T2FIT_MODEL_GAUSSIAN_RICIAN:
-      return fit_volume_kernel<T2FIT_SOLVER_LBFGSB, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN_RICIAN>;
-    default: return fit_volume_kernel<T2FIT_SOLVER_LBFGSB, T2FIT_PREC_F64, T2FIT_MODEL_RICIAN>;
-  }
+  return nullptr;  // the L-BFGS-B solver runs in the persistent kernel
+}
+
+template <int MODEL>
+hipError_t launch_persistent(unsigned grid, size_t lds, hipStream_t st, const LaneParams& P, const float* echoes,
+                             int layout, const uint8_t* mask, int64_t n_vox, const DevMaps& dm,
+                             unsigned long long* counter) {
+  auto kern = fit_lbfgsb_persistent_kernel<MODEL>;
+  // > 64 KiB of dynamic LDS (the correction pairs of 256 lanes) has to be opted into
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox, dm, counter);
+  return hipGetLastError();
 }
 
 int check_common(const t2fit_config* cfg, const void* echoes, int layout, int64_t n_vox) {
@@ -262,6 +402,13 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
   const unsigned grid = (unsigned)((n_vox + kBlock - 1) / kBlock);
   const size_t lds = (size_t)cfg->n_te * kLdsStride * sizeof(float);
   FitKernel kern = pick_kernel(*cfg);
+  const bool persistent = cfg->solver == T2FIT_SOLVER_LBFGSB;
+  if (persistent && n_vox >= 0xffffffffLL) return fail(T2FIT_E_INVALID, "n_vox must be below 2^32 per call");
+  unsigned long long* counter = nullptr;
+  if (persistent) {
+    T2_HIP(hipMallocAsync((void**)&counter, sizeof(unsigned long long), st));
+    T2_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
+  }
   if (g_timing) {
     if (!g_ev0) {
       T2_HIP(hipEventCreate(&g_ev0));
@@ -269,12 +416,34 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
     }
     T2_HIP(hipEventRecord(g_ev0, st));
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox, dm);
+  if (persistent) {
+    // one workgroup per CU slot; not required to be co-resident (work comes from an atomic queue)
+    const int64_t chunks = (n_vox + kChunk - 1) / kChunk;
+    const unsigned pgrid = (unsigned)std::min<int64_t>((chunks + 3) / 4, g_persistent_blocks);
+    const int np = cfg->model == T2FIT_MODEL_GAUSSIAN ? 2 : 3;
+    const size_t plds = (((size_t)cfg->n_te * kLdsStride + 1) & ~(size_t)1) * sizeof(float) +
+                        (size_t)2 * 10 * np * kBlock * sizeof(double) + (size_t)(kBlock / 64) * kQueueCap * sizeof(uint32_t);
+    hipError_t pe;
+    switch (cfg->model) {
+      case T2FIT_MODEL_GAUSSIAN:
+        pe = launch_persistent<T2FIT_MODEL_GAUSSIAN>(pgrid, plds, st, P, echoes, layout, mask, n_vox, dm, counter);
+        break;
+      case T2FIT_MODEL_GAUSSIAN_RICIAN:
+        pe = launch_persistent<T2FIT_MODEL_GAUSSIAN_RICIAN>(pgrid, plds, st, P, echoes, layout, mask, n_vox, dm, counter);
+        break;
+      default:
+        pe = launch_persistent<T2FIT_MODEL_RICIAN>(pgrid, plds, st, P, echoes, layout, mask, n_vox, dm, counter);
+    }
+    if (pe != hipSuccess) return fail(T2FIT_E_HIP, std::string("persistent fit launch: ") + hipGetErrorString(pe));
+  } else {
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox, dm);
+  }
   T2_HIP(hipGetLastError());
   if (g_timing) {
     T2_HIP(hipEventRecord(g_ev1, st));
     g_ev_valid = true;
   }
+  if (counter) T2_HIP(hipFreeAsync(counter, st));
   return T2FIT_OK;
 }
 

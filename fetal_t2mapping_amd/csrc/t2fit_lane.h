@@ -47,6 +47,7 @@ struct LaneResult {
   double x[3];  // k, T2, sigma
   double fun;
   int32_t nit;
+  int32_t nfev;  // objective evaluations (scipy result.nfev)
   uint8_t status;
 };
 
@@ -102,7 +103,7 @@ T2_HD double t2_chbevl(double x, const double* c, int n) {
 }
 
 T2_HD double t2_i0e(double x) {
-  const double A[30] = {
+  static const double A[30] = {
       -4.41534164647933937950E-18, 3.33079451882223809783E-17,  -2.43127984654795469359E-16,
       1.71539128555513303061E-15,  -1.16853328779934516808E-14, 7.67618549860493561688E-14,
       -4.85644678311192946090E-13, 2.95505266312963983461E-12,  -1.72682629144155570723E-11,
@@ -113,7 +114,7 @@ T2_HD double t2_i0e(double x) {
       1.63947561694133579842E-3,   -4.32430999505057594430E-3,  1.05464603945949983183E-2,
       -2.37374148058994688156E-2,  4.93052842396707084878E-2,   -9.49010970480476444210E-2,
       1.71620901522208775349E-1,   -3.04682672343198398683E-1,  6.76795274409476084995E-1};
-  const double B[25] = {
+  static const double B[25] = {
       -7.23318048787475395456E-18, -4.83050448594418207126E-18, 4.46562142029675999901E-17,
       3.46122286769746109310E-17,  -2.82762398051658348494E-16, -3.42548561967721913462E-16,
       1.77256013305652638360E-15,  3.81168066935262242075E-15,  -9.55484669882830764870E-15,

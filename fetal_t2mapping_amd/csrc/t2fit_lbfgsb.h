@@ -242,26 +242,64 @@ T2_HD void dcsrch(double f, double g, double& stp, double ftol, double gtol, dou
   s.task = LS_FG;
 }
 
+// numpy's float64 add.reduce order for a vector of n < 16 items, fed one item at a time:
+// n < 8 sequential from 0; otherwise ((t0+t1)+(t2+t3)) + ((t4+t5)+(t6+t7)), then t8.. one by one.
+// i and n are wave-uniform, so the switch is a scalar branch on the device.
+struct NpSum16 {
+  double p0, p1, p2, s;
+  T2_HD void add(int i, int n, double t) {
+    if (n < 8) { s = i == 0 ? 0.0 + t : s + t; return; }
+    switch (i) {
+      case 0: p0 = t; break;
+      case 1: p0 += t; break;
+      case 2: p1 = t; break;
+      case 3: p1 += t; p0 += p1; break;
+      case 4: p1 = t; break;
+      case 5: p1 += t; break;
+      case 6: p2 = t; break;
+      case 7: p2 += t; p1 += p2; s = p0 + p1; break;
+      default: s += t; break;
+    }
+  }
+};
+
 // ---- the solver -----------------------------------------------------------------------------------
+// Resumable (reverse-communication) form, like the library's own driver loop: the caller evaluates
+// the objective and its forward-difference gradient at `x` with eval(), then calls advance(), which
+// runs the solver up to the next point it needs evaluated (or to the end).  A persistent kernel can
+// therefore keep the expensive eval() uniform across the lanes of a wave while every lane sits in a
+// different phase (or a different voxel) of its own fit.
 template <int MODEL>
 struct Lbfgsb {
   static constexpr int N = MODEL == T2FIT_MODEL_GAUSSIAN ? 2 : 3;
   static constexpr int M = 10;
 
-  const ObjCtx& c;
-  const double* lb;
-  const double* ub;
-  int nfev;
+  double lb[N], ub[N];              // box
+  double x[N], g[N], f;             // current evaluation point, objective, FD gradient
+  double z[N], d[N], t[N], r[N];    // line-search frame: target, direction, x_old, g_old
+  double fold, gd, gdold, stp, stpmx, sbgnrm, theta;
+  LsState ls;
+  // correction pairs live outside the lane's registers: a ring of M slots of (s, y), element e of
+  // slot q at hist[(q*2N + e) * hstride].  In the kernel that is LDS (one column per lane, 480 B per
+  // lane for n = 3), which is what keeps the solver state within the VGPR budget.
+  double* hist;
+  int hstride, head;
+  int iwhere[N];
+  int col, nit, nfev, ifun;
+  uint8_t status;
+  bool first;
 
-  T2_HD Lbfgsb(const ObjCtx& c_, const double* lb_, const double* ub_) : c(c_), lb(lb_), ub(ub_), nfev(0) {}
-
-  // scipy ScalarFunction.fun_and_grad with approx_derivative('2-point', abs_step=h, bounds)
-  T2_HD void fg(const double* x, double& f, double* g) {
-    f = objective_t<MODEL>(c, x);
-    const double h0 = c.P->fd_step;
+  // scipy ScalarFunction.fun_and_grad with approx_derivative('2-point', abs_step=h, bounds): all N+1
+  // objective values in one pass over the echoes.  Evaluations that share T2 share their exp()
+  // (same inputs, same bits); the N+1 chains are independent, which is the instruction-level
+  // parallelism a lane needs at one wave per SIMD.
+  T2_HD void eval(const ObjCtx& c) {
+    const LaneParams& P = *c.P;
+    const int n = P.n_te;
+    double x1[N], dx[N];
     T2_UNROLL
     for (int i = 0; i < N; ++i) {
-      double h = h0;
+      double h = P.fd_step;
       if ((x[i] + h) - x[i] == 0.0)  // step lost to rounding: scipy falls back to sqrt(eps) relative
         h = 1.4901161193847656e-08 * (x[i] >= 0 ? 1.0 : -1.0) * t2_max(1.0, t2_abs(x[i]));
       const double lower = x[i] - lb[i], upper = ub[i] - x[i];
@@ -270,15 +308,79 @@ struct Lbfgsb {
       const bool fitting = t2_abs(h) <= t2_max(lower, upper);
       if (violated && fitting) h = -h;
       if (!fitting) h = upper >= lower ? upper : -lower;
-      double x1[N];
-      T2_UNROLL
-      for (int j = 0; j < N; ++j) x1[j] = x[j];
       x1[i] = x[i] + h;
-      const double dx = x1[i] - x[i];
-      const double df = objective_t<MODEL>(c, x1) - f;
-      g[i] = df / dx;
+      dx[i] = x1[i] - x[i];
     }
     nfev += 1 + N;
+    if (n >= 16) {  // long echo trains: one objective at a time (general pairwise summation)
+      f = objective_t<MODEL>(c, x);
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) {
+        double xt[N];
+        T2_UNROLL
+        for (int j = 0; j < N; ++j) xt[j] = j == i ? x1[j] : x[j];
+        g[i] = (objective_t<MODEL>(c, xt) - f) / dx[i];
+      }
+      return;
+    }
+    NpSum16 s0, s1, s2, s3;
+    s0.s = s1.s = s2.s = s3.s = 0.0;
+    if constexpr (MODEL == T2FIT_MODEL_GAUSSIAN) {
+      const double k = x[0], t2 = x[1], kp = x1[0], t2p = x1[1];
+      for (int i = 0; i < n; ++i) {
+        const double y = (double)c.sample(i), te = P.te[i];
+        const double E = t2_exp(-te / t2), Ep = t2_exp(-te / t2p);
+        const double r0 = y - k * E, r1 = y - kp * E, r2 = y - k * Ep;
+        s0.add(i, n, r0 * r0);
+        s1.add(i, n, r1 * r1);
+        s2.add(i, n, r2 * r2);
+      }
+      f = s0.s / n;
+      g[0] = (s1.s / n - f) / dx[0];
+      g[1] = (s2.s / n - f) / dx[1];
+    } else if constexpr (MODEL == T2FIT_MODEL_GAUSSIAN_RICIAN) {
+      const double k2 = x[0] * x[0], kp2 = x1[0] * x1[0], t2 = x[1], t2p = x1[1];
+      const double sg2 = x[N - 1] * x[N - 1], sgp2 = x1[N - 1] * x1[N - 1];
+      for (int i = 0; i < n; ++i) {
+        const double y = (double)c.sample(i), te = P.te[i];
+        const double E = t2_exp(-2.0 * te / t2), Ep = t2_exp(-2.0 * te / t2p);
+        const double r0 = y - t2_sqrt(k2 * E + sg2), r1 = y - t2_sqrt(kp2 * E + sg2);
+        const double r2 = y - t2_sqrt(k2 * Ep + sg2), r3 = y - t2_sqrt(k2 * E + sgp2);
+        s0.add(i, n, r0 * r0);
+        s1.add(i, n, r1 * r1);
+        s2.add(i, n, r2 * r2);
+        s3.add(i, n, r3 * r3);
+      }
+      f = s0.s / n;
+      g[0] = (s1.s / n - f) / dx[0];
+      g[1] = (s2.s / n - f) / dx[1];
+      g[N - 1] = (s3.s / n - f) / dx[N - 1];
+    } else {
+      const double k = x[0], kp = x1[0], t2 = x[1], t2p = x1[1];
+      const double sg2 = x[N - 1] * x[N - 1], sgp2 = x1[N - 1] * x1[N - 1];
+      const double ls2 = t2_log(sg2), lsp2 = t2_log(sgp2);
+      auto term = [](double kk, double E, double s2v, double ls2v, float yf) {
+        const double m = kk * E;
+        const double xx = (m * (double)yf) / s2v;
+        const double a = (double)logf(yf) - ls2v;
+        const double b = ((double)(yf * yf) + m * m) / (2.0 * s2v);
+        const double dd = (xx < 0 ? -xx : xx) + t2_log(t2_i0e(xx));
+        return (a - b) + dd;
+      };
+      for (int i = 0; i < n; ++i) {
+        const float yf = c.sample(i);
+        const double te = P.te[i];
+        const double E = t2_exp(-te / t2), Ep = t2_exp(-te / t2p);
+        s0.add(i, n, term(k, E, sg2, ls2, yf));
+        s1.add(i, n, term(kp, E, sg2, ls2, yf));
+        s2.add(i, n, term(k, Ep, sg2, ls2, yf));
+        s3.add(i, n, term(k, E, sgp2, lsp2, yf));
+      }
+      f = -s0.s;
+      g[0] = (-s1.s - f) / dx[0];
+      g[1] = (-s2.s - f) / dx[1];
+      g[N - 1] = (-s3.s - f) / dx[N - 1];
+    }
   }
 
   T2_HD double projgr(const double* x, const double* g) const {
@@ -293,31 +395,33 @@ struct Lbfgsb {
     return nrm;
   }
 
+  T2_HD double& hs(int p, int i) const { return hist[((((head + p) % M) * 2) * N + i) * hstride]; }
+  T2_HD double& hy(int p, int i) const { return hist[((((head + p) % M) * 2 + 1) * N + i) * hstride]; }
+
   // B = theta*I updated by the stored pairs, oldest first.
-  T2_HD static void build_b(double theta, const double (*S)[N], const double (*Y)[N], int col, double (*B)[N]) {
+  T2_HD void build_b(double (*B)[N]) const {
     T2_UNROLL
     for (int i = 0; i < N; ++i)
       T2_UNROLL
       for (int j = 0; j < N; ++j) B[i][j] = i == j ? theta : 0.0;
-    T2_UNROLL
-    for (int p = 0; p < M; ++p) {
-      if (p < col) {
-        double bs[N];
-        double sbs = 0.0, ys = 0.0;
+    for (int p = 0; p < col; ++p) {
+      double sp[N], yp[N], bs[N];
+      double sbs = 0.0, ys = 0.0;
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) { sp[i] = hs(p, i); yp[i] = hy(p, i); }
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) {
+        double a = 0.0;
         T2_UNROLL
-        for (int i = 0; i < N; ++i) {
-          double a = 0.0;
-          T2_UNROLL
-          for (int j = 0; j < N; ++j) a += B[i][j] * S[p][j];
-          bs[i] = a;
-        }
-        T2_UNROLL
-        for (int i = 0; i < N; ++i) { sbs += S[p][i] * bs[i]; ys += Y[p][i] * S[p][i]; }
-        T2_UNROLL
-        for (int i = 0; i < N; ++i)
-          T2_UNROLL
-          for (int j = 0; j < N; ++j) B[i][j] += Y[p][i] * Y[p][j] / ys - bs[i] * bs[j] / sbs;
+        for (int j = 0; j < N; ++j) a += B[i][j] * sp[j];
+        bs[i] = a;
       }
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) { sbs += sp[i] * bs[i]; ys += yp[i] * sp[i]; }
+      T2_UNROLL
+      for (int i = 0; i < N; ++i)
+        T2_UNROLL
+        for (int j = 0; j < N; ++j) B[i][j] += yp[i] * yp[j] / ys - bs[i] * bs[j] / sbs;
     }
   }
 
@@ -501,34 +605,42 @@ struct Lbfgsb {
     return true;
   }
 
-  T2_HD void run(LaneResult& out) {
-    const LaneParams& P = *c.P;
-    const double epsmch = 2.220446049250313e-16;
-    const double tol = (P.ftol / epsmch) * epsmch;  // factr * epsmch
-    const double pgtol = P.gtol;
-    double x[N], g[N], f;
-    int iwhere[N];
+  // Start a fit: x = x0 clipped into the box (scipy), empty memory.  Next: eval(), then advance().
+  // `hist_` must hold 2*M*N doubles at stride `hstride_`.
+  T2_HD void init(const LaneParams& P, const double* lb_, const double* ub_, double* hist_, int hstride_) {
+    hist = hist_;
+    hstride = hstride_;
+    head = 0;
     T2_UNROLL
     for (int i = 0; i < N; ++i) {
+      lb[i] = lb_[i];
+      ub[i] = ub_[i];
       x[i] = t2_clip(P.x0[i], lb[i], ub[i]);
       iwhere[i] = (ub[i] - lb[i] <= 0.0) ? 3 : 0;
     }
-    double S[M][N], Y[M][N];
+    col = 0; nit = 0; nfev = 0; ifun = 0;
+    theta = 1.0;
+    status = T2FIT_ST_NOT_CONV;
+    first = true;
+  }
+
+  // Line search could not be completed: back to the previous iterate.  With an empty memory that is
+  // scipy's ABNORMAL termination (success False); otherwise drop the memory and redo the iteration.
+  T2_HD bool line_search_failed(const LaneParams& P) {
     T2_UNROLL
-    for (int p = 0; p < M; ++p)
-      T2_UNROLL
-      for (int i = 0; i < N; ++i) { S[p][i] = 0.0; Y[p][i] = 0.0; }
-    int col = 0, nit = 0;
-    double theta = 1.0;
-    uint8_t status = T2FIT_ST_NOT_CONV;
-    fg(x, f, g);
-    double sbgnrm = projgr(x, g);
-    bool done = sbgnrm <= pgtol;
-    if (done) status = T2FIT_ST_CONVERGED;
-    while (!done) {
+    for (int i = 0; i < N; ++i) { x[i] = t[i]; g[i] = r[i]; }
+    f = fold;
+    if (col == 0) return true;
+    col = 0; theta = 1.0;
+    return begin_iteration(P);
+  }
+
+  // Cauchy point, subspace minimisation, line-search set-up and its first trial point.
+  // Returns true if the fit ended, false if `x` now holds a point to evaluate.
+  T2_HD bool begin_iteration(const LaneParams& P) {
+    for (;;) {
       double B[N][N];
-      build_b(theta, S, Y, col, B);
-      double z[N];
+      build_b(B);
       cauchy(x, g, B, theta, sbgnrm, iwhere, z);
       int nfree = 0;
       T2_UNROLL
@@ -540,11 +652,9 @@ struct Lbfgsb {
         }
       }
       // ---- line search along d = z - x (lnsrlb) ----
-      double d[N], t[N], r[N];
-      double dtd = 0.0;
       T2_UNROLL
-      for (int i = 0; i < N; ++i) { d[i] = z[i] - x[i]; dtd += d[i] * d[i]; t[i] = x[i]; r[i] = g[i]; }
-      double stpmx = 1e10;
+      for (int i = 0; i < N; ++i) { d[i] = z[i] - x[i]; t[i] = x[i]; r[i] = g[i]; }
+      stpmx = 1e10;
       if (nit == 0) {
         stpmx = 1.0;
       } else {
@@ -562,92 +672,117 @@ struct Lbfgsb {
           }
         }
       }
-      double stp = 1.0;  // every variable is boxed, so the first step is not rescaled by 1/|d|
-      const double fold = f;
-      double gd = 0.0, gdold = 0.0;
-      int ifun = 0;
-      bool ls_fail = false;
-      LsState ls;
+      stp = 1.0;  // every variable is boxed, so the first step is not rescaled by 1/|d|
+      fold = f;
+      ifun = 0;
       ls.task = LS_START;
-      for (;;) {
-        gd = 0.0;
-        T2_UNROLL
-        for (int i = 0; i < N; ++i) gd += g[i] * d[i];
-        if (ifun == 0) {
-          gdold = gd;
-          if (gd >= 0.0) { ls_fail = true; break; }  // not a descent direction
-        }
+      gd = 0.0;
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) gd += g[i] * d[i];
+      gdold = gd;
+      bool fail = gd >= 0.0;  // not a descent direction
+      if (!fail) {
         dcsrch(f, gd, stp, 1e-3, 0.9, 0.1, 0.0, stpmx, ls);
-        if (ls.task == LS_CONV || ls.task == LS_WARN) break;
-        if (ls.task == LS_ERROR) { ls_fail = true; break; }
-        ++ifun;
-        if (ifun - 1 >= P.maxls) { ls_fail = true; break; }
-        T2_UNROLL
-        for (int i = 0; i < N; ++i) x[i] = stp == 1.0 ? z[i] : stp * d[i] + t[i];
-        fg(x, f, g);
+        fail = ls.task != LS_FG;  // START can only answer FG or ERROR
       }
-      if (ls_fail) {
-        T2_UNROLL
-        for (int i = 0; i < N; ++i) { x[i] = t[i]; g[i] = r[i]; }
-        f = fold;
-        if (col == 0) break;  // abnormal termination in the line search: success False
+      if (!fail) {
+        ifun = 1;
+        fail = ifun - 1 >= P.maxls;
+      }
+      if (fail) {
+        // x, f, g are still the previous iterate here
+        if (col == 0) return true;
         col = 0; theta = 1.0;
         continue;
       }
-      ++nit;
-#if !defined(__HIP_DEVICE_COMPILE__)
-      if (c.trace && *c.trace_n < c.trace_cap) {
-        double* tr = c.trace + 4 * (*c.trace_n)++;
-        tr[0] = x[0]; tr[1] = x[1]; tr[2] = N == 3 ? x[N - 1] : 0.0; tr[3] = f;
-      }
-#endif
-      sbgnrm = projgr(x, g);
-      if (nit >= P.maxiter || nfev > P.maxfun) break;  // scipy: STOP, success False
-      if (sbgnrm <= pgtol) { status = T2FIT_ST_CONVERGED; break; }
-      if ((fold - f) <= tol * t2_max3(t2_abs(fold), t2_abs(f), 1.0)) { status = T2FIT_ST_CONVERGED; break; }
-      // ---- correction pair ----
-      double rr = 0.0, dr, ddum;
       T2_UNROLL
-      for (int i = 0; i < N; ++i) { r[i] = g[i] - r[i]; rr += r[i] * r[i]; }
-      if (stp == 1.0) {
-        dr = gd - gdold;
-        ddum = -gdold;
-      } else {
-        dr = (gd - gdold) * stp;
-        T2_UNROLL
-        for (int i = 0; i < N; ++i) d[i] *= stp;
-        ddum = -gdold * stp;
-      }
-      if (dr <= epsmch * ddum) continue;  // curvature too small: skip the update
-      if (col == M) {
-        T2_UNROLL
-        for (int p = 0; p + 1 < M; ++p)
-          T2_UNROLL
-          for (int i = 0; i < N; ++i) { S[p][i] = S[p + 1][i]; Y[p][i] = Y[p + 1][i]; }
+      for (int i = 0; i < N; ++i) x[i] = stp == 1.0 ? z[i] : stp * d[i] + t[i];
+      return false;
+    }
+  }
+
+  // A trial point of the line search has been evaluated.
+  T2_HD bool advance(const ObjCtx& c) {
+    const LaneParams& P = *c.P;
+    const double epsmch = 2.220446049250313e-16;
+    if (first) {
+      first = false;
+      sbgnrm = projgr(x, g);
+      if (sbgnrm <= P.gtol) { status = T2FIT_ST_CONVERGED; return true; }
+      return begin_iteration(P);
+    }
+    gd = 0.0;
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) gd += g[i] * d[i];
+    dcsrch(f, gd, stp, 1e-3, 0.9, 0.1, 0.0, stpmx, ls);
+    if (ls.task == LS_ERROR) return line_search_failed(P);
+    if (ls.task == LS_FG) {
+      ++ifun;
+      if (ifun - 1 >= P.maxls) return line_search_failed(P);
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) x[i] = stp == 1.0 ? z[i] : stp * d[i] + t[i];
+      return false;
+    }
+    // ---- new iterate ----
+    ++nit;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (c.trace && *c.trace_n < c.trace_cap) {
+      double* tr = c.trace + 4 * (*c.trace_n)++;
+      tr[0] = x[0]; tr[1] = x[1]; tr[2] = N == 3 ? x[N - 1] : 0.0; tr[3] = f;
+    }
+#endif
+    sbgnrm = projgr(x, g);
+    if (nit >= P.maxiter || nfev > P.maxfun) return true;  // scipy: STOP, success False
+    if (sbgnrm <= P.gtol) { status = T2FIT_ST_CONVERGED; return true; }
+    const double tol = (P.ftol / epsmch) * epsmch;  // factr * epsmch
+    if ((fold - f) <= tol * t2_max3(t2_abs(fold), t2_abs(f), 1.0)) { status = T2FIT_ST_CONVERGED; return true; }
+    // ---- correction pair ----
+    double rr = 0.0, dr, ddum;
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) { r[i] = g[i] - r[i]; rr += r[i] * r[i]; }
+    if (stp == 1.0) {
+      dr = gd - gdold;
+      ddum = -gdold;
+    } else {
+      dr = (gd - gdold) * stp;
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) d[i] *= stp;
+      ddum = -gdold * stp;
+    }
+    if (!(dr <= epsmch * ddum)) {  // else: curvature too small, skip the update
+      if (col == M) {  // ring is full: the oldest pair is dropped
+        head = (head + 1) % M;
         col = M - 1;
       }
       T2_UNROLL
-      for (int p = 0; p < M; ++p)
-        if (p == col)
-          T2_UNROLL
-          for (int i = 0; i < N; ++i) { S[p][i] = d[i]; Y[p][i] = r[i]; }
+      for (int i = 0; i < N; ++i) { hs(col, i) = d[i]; hy(col, i) = r[i]; }
       ++col;
       theta = rr / dr;
     }
+    return begin_iteration(P);
+  }
+
+  T2_HD void result(LaneResult& out) const {
     T2_UNROLL
     for (int i = 0; i < 3; ++i) out.x[i] = 0.0;
     T2_UNROLL
     for (int i = 0; i < N; ++i) out.x[i] = x[i];
     out.fun = f;
     out.nit = nit;
+    out.nfev = nfev;
     out.status = status;
   }
 };
 
 template <int MODEL>
 T2_HD void lbfgsb_solve(const ObjCtx& c, const double* lb, const double* ub, LaneResult& out) {
-  Lbfgsb<MODEL> s(c, lb, ub);
-  s.run(out);
+  Lbfgsb<MODEL> s;
+  double hist[2 * Lbfgsb<MODEL>::M * Lbfgsb<MODEL>::N];
+  s.init(*c.P, lb, ub, hist, 1);
+  do {
+    s.eval(c);
+  } while (!s.advance(c));
+  s.result(out);
 }
 
 }  // namespace t2fit

@@ -200,6 +200,7 @@ T2_HD void lm_solve(const ObjCtx& c, const double* lbd, const double* ubd, LaneR
   out.x[2] = (NP == 3) ? (double)q[2] : 0.0;
   out.fun = (double)e.f / n;
   out.nit = it;
+  out.nfev = it + 1;
   out.status = status;
 }
 

@@ -2,6 +2,8 @@
 // that solver logic can be checked against the golden fixtures where no GPU exists.  It is built
 // by tests/hostsim/build.py into tests/hostsim/libt2fit_hostsim.so and loaded only by tests/;
 // the product package never loads it and has no CPU execution path.
+#include <stdlib.h>
+
 #include "../../fetal_t2mapping_amd/csrc/t2fit_config.h"
 #include "../../fetal_t2mapping_amd/csrc/t2fit_dispatch.h"
 
@@ -28,6 +30,7 @@ extern "C" int hostsim_fit_rows(const t2fit_config* cfg, const float* rows, int6
     fun[v] = r.fun;
     nit[v] = r.nit;
     status[v] = r.status;
+    if (getenv("T2_HOSTSIM_NFEV")) nit[v] = r.nfev;  // debugging aid: report evaluations instead of iterations
     if (res) res[v] = o.res;
     if (r2) r2[v] = o.r2;
   }
