@@ -34,34 +34,37 @@ struct LaneOutputs {
   uint8_t status;
 };
 
-T2_HD ObjCtx make_ctx(const LaneParams& P, EchoView y, bool& finite) {
+// Check one voxel's samples (stored at col[i*stride]) and turn them into what the objective sees:
+// divided in place by their maximum when cfg.norm (float32 / float32, as numpy does).  y0_raw is
+// the first sample before normalisation: the no-prior lower bound of k uses it (run_t2mapping.py:244).
+T2_HD ObjCtx prepare_samples(const LaneParams& P, float* col, int stride, bool& finite, float& y0_raw) {
   const int n = P.n_te;
-  ObjCtx c;
-  c.P = &P;
-  c.y = y;
-  c.norm = P.norm != 0;
-  c.ymax = 1.0f;
   finite = true;
-  float ymax = y[0];
+  y0_raw = col[0];
+  float ymax = col[0];
   for (int i = 0; i < n; ++i) {
-    const float v = y[i];
+    const float v = col[i * stride];
     finite = finite && t2_finite(v);
     ymax = v > ymax ? v : ymax;
   }
-  if (c.norm) {
-    c.ymax = ymax;
-    for (int i = 0; i < n; ++i) finite = finite && t2_finite(c.sample(i));
+  if (P.norm) {
+    for (int i = 0; i < n; ++i) {
+      const float v = col[i * stride] / ymax;
+      col[i * stride] = v;
+      finite = finite && t2_finite(v);
+    }
   }
+  ObjCtx c;
+  c.P = &P;
+  c.y = EchoView{col, stride};
   return c;
 }
 
 template <int SOLVER, int PREC, int MODEL>
-T2_HD void fit_lane_t(const LaneParams& P, EchoView y, LaneResult& r) {
+T2_HD void fit_lane_t(const LaneParams& P, const ObjCtx& c, bool finite, float y0_raw, LaneResult& r) {
   constexpr int NP = MODEL == T2FIT_MODEL_GAUSSIAN ? 2 : 3;
-  bool finite;
-  const ObjCtx c = make_ctx(P, y, finite);
   double lb[3], ub[3];
-  const bool feasible = lane_bounds(P, y[0], lb, ub);
+  const bool feasible = lane_bounds(P, y0_raw, lb, ub);
   r.nit = 0;
   r.nfev = 0;
   r.fun = NAN;
@@ -88,27 +91,45 @@ T2_HD void fit_lane_t(const LaneParams& P, EchoView y, LaneResult& r) {
 }
 
 // runtime switch (host simulator); the kernels pick the instantiation at launch time instead
-T2_HD void fit_lane(const LaneParams& P, EchoView y, LaneResult& r) {
+T2_HD void fit_lane(const LaneParams& P, const ObjCtx& c, bool finite, float y0_raw, LaneResult& r) {
   if (P.solver == T2FIT_SOLVER_LM) {
     if (P.precision == T2FIT_PREC_F32) {
-      if (P.model == T2FIT_MODEL_GAUSSIAN) fit_lane_t<T2FIT_SOLVER_LM, T2FIT_PREC_F32, T2FIT_MODEL_GAUSSIAN>(P, y, r);
-      else fit_lane_t<T2FIT_SOLVER_LM, T2FIT_PREC_F32, T2FIT_MODEL_GAUSSIAN_RICIAN>(P, y, r);
+      if (P.model == T2FIT_MODEL_GAUSSIAN) fit_lane_t<T2FIT_SOLVER_LM, T2FIT_PREC_F32, T2FIT_MODEL_GAUSSIAN>(P, c, finite, y0_raw, r);
+      else fit_lane_t<T2FIT_SOLVER_LM, T2FIT_PREC_F32, T2FIT_MODEL_GAUSSIAN_RICIAN>(P, c, finite, y0_raw, r);
     } else {
-      if (P.model == T2FIT_MODEL_GAUSSIAN) fit_lane_t<T2FIT_SOLVER_LM, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN>(P, y, r);
-      else fit_lane_t<T2FIT_SOLVER_LM, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN_RICIAN>(P, y, r);
+      if (P.model == T2FIT_MODEL_GAUSSIAN) fit_lane_t<T2FIT_SOLVER_LM, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN>(P, c, finite, y0_raw, r);
+      else fit_lane_t<T2FIT_SOLVER_LM, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN_RICIAN>(P, c, finite, y0_raw, r);
     }
   } else {
-    if (P.model == T2FIT_MODEL_GAUSSIAN) fit_lane_t<T2FIT_SOLVER_LBFGSB, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN>(P, y, r);
-    else if (P.model == T2FIT_MODEL_GAUSSIAN_RICIAN) fit_lane_t<T2FIT_SOLVER_LBFGSB, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN_RICIAN>(P, y, r);
-    else fit_lane_t<T2FIT_SOLVER_LBFGSB, T2FIT_PREC_F64, T2FIT_MODEL_RICIAN>(P, y, r);
+    if (P.model == T2FIT_MODEL_GAUSSIAN) fit_lane_t<T2FIT_SOLVER_LBFGSB, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN>(P, c, finite, y0_raw, r);
+    else if (P.model == T2FIT_MODEL_GAUSSIAN_RICIAN) fit_lane_t<T2FIT_SOLVER_LBFGSB, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN_RICIAN>(P, c, finite, y0_raw, r);
+    else fit_lane_t<T2FIT_SOLVER_LBFGSB, T2FIT_PREC_F64, T2FIT_MODEL_RICIAN>(P, c, finite, y0_raw, r);
   }
 }
 
-// Epilogue: float32 map values, residual map and optional R^2 from the float32 parameters
-// (run_t2mapping.py:456-458 casts, utils/t2map_utils.py:62-89).
-T2_HD void lane_epilogue(const LaneParams& P, EchoView y, const LaneResult& r, LaneOutputs& o, bool want_r2) {
-  bool finite;
-  const ObjCtx c = make_ctx(P, y, finite);
+// Coefficient of determination about the mean (formula of the reference's notebook,
+// notebooks/20240924_ada_qmri_jmri_invitro.ipynb:345-347).  No reference map exists for it: extension.
+T2_HD float r_squared(const ObjCtx& c, double k, double t2, double sg) {
+  const LaneParams& P = *c.P;
+  const int n = P.n_te;
+  double mean = 0.0;
+  for (int i = 0; i < n; ++i) mean += (double)c.sample(i);
+  mean /= n;
+  double ss_tot = 0.0, ss_res = 0.0;
+  const bool sq = P.model == T2FIT_MODEL_GAUSSIAN_RICIAN;
+  for (int i = 0; i < n; ++i) {
+    const double yi = (double)c.sample(i);
+    const double E = t2_exp(-P.te[i] / t2);
+    const double m = sq ? t2_sqrt(k * k * E * E + sg * sg) : k * E;
+    ss_res += (yi - m) * (yi - m);
+    ss_tot += (yi - mean) * (yi - mean);
+  }
+  return (float)(1.0 - ss_res / ss_tot);
+}
+
+// Epilogue: float32 map values (run_t2mapping.py:456-458 casts), then the residual map and the
+// optional R^2 evaluated from those float32 maps (utils/t2map_utils.py:62-89).
+T2_HD void lane_epilogue(const ObjCtx& c, const LaneResult& r, LaneOutputs& o, bool want_r2) {
   o.k = (float)r.x[0];
   o.t2 = (float)r.x[1];
   o.sigma = (float)r.x[2];
@@ -116,25 +137,7 @@ T2_HD void lane_epilogue(const LaneParams& P, EchoView y, const LaneResult& r, L
   o.nit = r.nit;
   o.status = r.status;
   o.res = residual_mean(c, o.k, o.t2, o.sigma);
-  o.r2 = 0.0f;
-  if (want_r2) {
-    // coefficient of determination about the mean (formula of the reference's notebook,
-    // notebooks/20240924_ada_qmri_jmri_invitro.ipynb:345-347); no reference map exists for it
-    const int n = P.n_te;
-    double mean = 0.0;
-    for (int i = 0; i < n; ++i) mean += (double)c.sample(i);
-    mean /= n;
-    double ss_tot = 0.0, ss_res = 0.0;
-    const bool sq = P.model == T2FIT_MODEL_GAUSSIAN_RICIAN;
-    for (int i = 0; i < n; ++i) {
-      const double yi = (double)c.sample(i);
-      const double E = t2_exp(-P.te[i] / r.x[1]);
-      const double m = sq ? t2_sqrt(r.x[0] * r.x[0] * E * E + r.x[2] * r.x[2]) : r.x[0] * E;
-      ss_res += (yi - m) * (yi - m);
-      ss_tot += (yi - mean) * (yi - mean);
-    }
-    o.r2 = (float)(1.0 - ss_res / ss_tot);
-  }
+  o.r2 = want_r2 ? r_squared(c, (double)o.k, (double)o.t2, (double)o.sigma) : 0.0f;
 }
 
 }  // namespace t2fit

@@ -99,6 +99,16 @@ __device__ __forceinline__ void store_result(const DevMaps& m, int64_t v, const 
   if (m.fund) m.fund[v] = r.fun;
 }
 
+// parameters and per-voxel extras only; res / r2 come from the epilogue pass
+__device__ __forceinline__ void store_fit(const DevMaps& m, int64_t v, const LaneResult& r) {
+  m.k[v] = (float)r.x[0]; m.t2[v] = (float)r.x[1]; m.sigma[v] = (float)r.x[2];
+  if (m.fun) m.fun[v] = (float)r.fun;
+  if (m.nit) m.nit[v] = r.nit;
+  if (m.status) m.status[v] = r.status;
+  if (m.xd) { m.xd[3 * v] = r.x[0]; m.xd[3 * v + 1] = r.x[1]; m.xd[3 * v + 2] = r.x[2]; }
+  if (m.fund) m.fund[v] = r.fun;
+}
+
 // One lane per voxel, one voxel per lane: used for the LM solver and as the fallback of the
 // persistent kernel below.
 template <int SOLVER, int PREC, int MODEL>
@@ -117,11 +127,13 @@ __global__ __launch_bounds__(kBlock) void fit_volume_kernel(const LaneParams P, 
     store_masked(m, v);
     return;
   }
-  const EchoView y{lds + lane, kLdsStride};
+  bool finite;
+  float y0_raw;
+  const ObjCtx c = prepare_samples(P, lds + lane, kLdsStride, finite, y0_raw);
   LaneResult r;
-  fit_lane_t<SOLVER, PREC, MODEL>(P, y, r);
+  fit_lane_t<SOLVER, PREC, MODEL>(P, c, finite, y0_raw, r);
   LaneOutputs o;
-  lane_epilogue(P, y, r, o, m.r2 != nullptr);
+  lane_epilogue(c, r, o, m.r2 != nullptr);
   store_result(m, v, o, r);
 }
 
@@ -157,8 +169,10 @@ __global__ __launch_bounds__(kBlock) void fit_lbfgsb_persistent_kernel(const Lan
   ObjCtx c;
   c.P = &P;
   c.y = y;
-  c.norm = P.norm != 0;
-  c.ymax = 1.0f;
+  // table start point and bounds: uniform, read once
+  double box_x0[3], box_lb[3], box_ub[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { box_x0[j] = P.x0[j]; box_lb[j] = P.lb[j]; box_ub[j] = P.ub[j]; }
   for (;;) {
     const unsigned long long need = __ballot(!busy);
     if (need) {
@@ -175,15 +189,24 @@ __global__ __launch_bounds__(kBlock) void fit_lbfgsb_persistent_kernel(const Lan
           if (lane < q_count) queue[lane] = tmp;
           q_head = 0;
         }
+        // all mask bytes of the chunk first (independent loads, one latency), then the queue
+        // pushes, then the zero stores of the masked-out voxels
+        bool act[kChunk / 64];
 #pragma unroll
         for (int q = 0; q < kChunk / 64; ++q) {
           const int64_t vv = base + q * 64 + lane;
-          const bool in = vv < n_vox;
-          const bool act = in && (mask == nullptr || mask[vv] != 0);
-          if (in && !act) store_masked(m, vv);
-          const unsigned long long b = __ballot(act);
-          if (act) queue[q_count + __popcll(b & lt_mask)] = (uint32_t)vv;
+          act[q] = vv < n_vox && (mask == nullptr || mask[vv] != 0);
+        }
+#pragma unroll
+        for (int q = 0; q < kChunk / 64; ++q) {
+          const unsigned long long b = __ballot(act[q]);
+          if (act[q]) queue[q_count + __popcll(b & lt_mask)] = (uint32_t)(base + q * 64 + lane);
           q_count += __popcll(b);
+        }
+#pragma unroll
+        for (int q = 0; q < kChunk / 64; ++q) {
+          const int64_t vv = base + q * 64 + lane;
+          if (vv < n_vox && !act[q]) store_masked(m, vv);
         }
       }
       bool fresh = false;
@@ -199,29 +222,55 @@ __global__ __launch_bounds__(kBlock) void fit_lbfgsb_persistent_kernel(const Lan
       q_head += taken;
       q_count -= taken;
       if (fresh) {
-        // this lane's samples into its LDS column
-        if (layout == T2FIT_LAYOUT_TE_MAJOR) {
-          for (int i = 0; i < P.n_te; ++i) col[i * kLdsStride] = echoes[(int64_t)i * n_vox + v];
-        } else {
-          for (int i = 0; i < P.n_te; ++i) col[i * kLdsStride] = echoes[v * P.n_te + i];
+        // this lane's samples: up to 8 loads in flight, checked in registers, parked in its LDS
+        // column (already divided by the row maximum when cfg.norm, run_t2mapping.py:237-238)
+        bool finite = true;
+        float ymax = 0.0f, y0 = 0.0f;
+        const int n_te = P.n_te;
+        for (int i0 = 0; i0 < n_te; i0 += 8) {
+          float tmp[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (i0 + j < n_te)
+              tmp[j] = layout == T2FIT_LAYOUT_TE_MAJOR ? echoes[(int64_t)(i0 + j) * n_vox + v]
+                                                       : echoes[v * n_te + (i0 + j)];
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (i0 + j < n_te) {
+              const float sv = tmp[j];
+              col[(i0 + j) * kLdsStride] = sv;
+              finite = finite && t2_finite(sv);
+              if (i0 + j == 0) { y0 = sv; ymax = sv; }
+              ymax = sv > ymax ? sv : ymax;
+            }
         }
-        bool finite;
-        const ObjCtx cc = make_ctx(P, y, finite);
-        c.ymax = cc.ymax;
+        if (P.norm) {
+          for (int i = 0; i < n_te; ++i) {
+            const float sv = col[i * kLdsStride] / ymax;
+            col[i * kLdsStride] = sv;
+            finite = finite && t2_finite(sv);
+          }
+        }
         double lb[3], ub[3];
-        const bool feasible = lane_bounds(P, y[0], lb, ub);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { lb[j] = box_lb[j]; ub[j] = box_ub[j]; }
+        if (P.no_prior) {  // run_t2mapping.py:243-245
+          lb[0] = (double)y0; ub[0] = P.np_k_ub;
+          lb[1] = P.np_t2_lb; ub[1] = P.np_t2_ub;
+        }
+        bool feasible = true;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) feasible = feasible && !(lb[j] > ub[j]);
         if (!feasible || !finite) {  // nothing to iterate on (fit_lane_t documents both cases)
           LaneResult r;
           r.nit = 0; r.nfev = 0; r.fun = NAN;
           for (int j = 0; j < 3; ++j)
-            r.x[j] = !feasible ? (j < NP ? NAN : 0.0) : (j < NP ? t2_clip(P.x0[j], lb[j], ub[j]) : 0.0);
+            r.x[j] = !feasible ? (j < NP ? NAN : 0.0) : (j < NP ? t2_clip(box_x0[j], lb[j], ub[j]) : 0.0);
           r.status = !feasible ? T2FIT_ST_INFEASIBLE : T2FIT_ST_NONFINITE;
-          LaneOutputs o;
-          lane_epilogue(P, y, r, o, m.r2 != nullptr);
-          store_result(m, v, o, r);
+          store_fit(m, v, r);
           busy = false;
         } else {
-          s.init(P, lb, ub, hist, kBlock);
+          s.init(box_x0, lb, ub, hist, kBlock);
         }
       }
     }
@@ -234,21 +283,22 @@ __global__ __launch_bounds__(kBlock) void fit_lbfgsb_persistent_kernel(const Lan
       if (s.advance(c)) {
         LaneResult r;
         s.result(r);
-        LaneOutputs o;
-        lane_epilogue(P, y, r, o, m.r2 != nullptr);
-        store_result(m, v, o, r);
+        store_fit(m, v, r);
         busy = false;
       }
     }
   }
 }
 
-// Residual map only (utils/t2map_utils.py:62-89) from float32 maps already on the device.
+// Residual map (utils/t2map_utils.py:62-89) and optional R^2 from float32 maps already on the device.
+// Also the second, fully uniform pass of the reference-trajectory fit: the persistent kernel stores
+// t2/k/sigma only, because a lane that evaluated 8 float64 exp() for one finished voxel would hold
+// up the other 63 lanes of its wave.
 __global__ __launch_bounds__(kBlock) void residuals_kernel(const LaneParams P, const float* __restrict__ echoes,
                                                            int layout, const uint8_t* __restrict__ mask,
                                                            int64_t n_vox, const float* __restrict__ t2,
                                                            const float* __restrict__ k,
-                                                           const float* __restrict__ sigma, float* res) {
+                                                           const float* __restrict__ sigma, float* res, float* r2) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x;
   const int64_t base = (int64_t)blockIdx.x * kBlock;
@@ -257,14 +307,17 @@ __global__ __launch_bounds__(kBlock) void residuals_kernel(const LaneParams P, c
   const bool active = in_range && (mask == nullptr || mask[v] != 0);
   stage_echoes(lds, echoes, layout, P.n_te, n_vox, base, active);
   if (!in_range) return;
-  float out = 0.0f;
+  float out = 0.0f, out2 = 0.0f;
   if (active) {
-    const EchoView y{lds + lane, kLdsStride};
     bool finite;
-    const ObjCtx c = make_ctx(P, y, finite);
-    out = residual_mean(c, k[v], t2[v], sigma ? sigma[v] : 0.0f);
+    float y0_raw;
+    const ObjCtx c = prepare_samples(P, lds + lane, kLdsStride, finite, y0_raw);
+    const float kv = k[v], tv = t2[v], sv = sigma ? sigma[v] : 0.0f;
+    out = residual_mean(c, kv, tv, sv);
+    if (r2) out2 = r_squared(c, (double)kv, (double)tv, (double)sv);
   }
   res[v] = out;
+  if (r2) r2[v] = out2;
 }
 
 // ---- union mask + ordered flat indices (run_t2mapping.py:383-384,412,421) ----------------------
@@ -435,11 +488,17 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
         pe = launch_persistent<T2FIT_MODEL_RICIAN>(pgrid, plds, st, P, echoes, layout, mask, n_vox, dm, counter);
     }
     if (pe != hipSuccess) return fail(T2FIT_E_HIP, std::string("persistent fit launch: ") + hipGetErrorString(pe));
+    if (g_timing) {  // the timed kernel is the fit; the epilogue pass is a separate, HBM-bound launch
+      T2_HIP(hipEventRecord(g_ev1, st));
+      g_ev_valid = true;
+    }
+    hipLaunchKernelGGL(residuals_kernel, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox,
+                       (const float*)dm.t2, (const float*)dm.k, (const float*)dm.sigma, dm.res, dm.r2);
   } else {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox, dm);
   }
   T2_HIP(hipGetLastError());
-  if (g_timing) {
+  if (g_timing && !persistent) {
     T2_HIP(hipEventRecord(g_ev1, st));
     g_ev_valid = true;
   }
@@ -625,7 +684,7 @@ int t2fit_residuals_dev(const t2fit_config* cfg, const float* echoes_dev, int la
   const unsigned grid = (unsigned)((n_vox + kBlock - 1) / kBlock);
   const size_t lds = (size_t)cfg->n_te * kLdsStride * sizeof(float);
   hipLaunchKernelGGL(residuals_kernel, dim3(grid), dim3(kBlock), lds, (hipStream_t)stream, P, echoes_dev, layout,
-                     mask_dev, n_vox, t2, k, sigma, res);
+                     mask_dev, n_vox, t2, k, sigma, res, (float*)nullptr);
   T2_HIP(hipGetLastError());
   return T2FIT_OK;
 }

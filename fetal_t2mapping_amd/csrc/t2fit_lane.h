@@ -130,16 +130,15 @@ T2_HD double t2_i0e(double x) {
 }
 
 // ---- objective values exactly in the reference's operation order (float64) ---------------------
-// y_scale: 1/max(y) when cfg.norm (run_t2mapping.py:237-238 divides in float32), else unused.
+// `y` holds the samples as the objective sees them: when cfg.norm they have already been divided by
+// the voxel's maximum in float32 (run_t2mapping.py:237-238), see prepare_samples().
 struct ObjCtx {
   const LaneParams* P;
   EchoView y;
-  bool norm;
-  float ymax;
   double* trace = nullptr;  // optional (host simulator only): x, f per iteration, 4 doubles each
   int trace_cap = 0;
   int* trace_n = nullptr;
-  T2_HD float sample(int i) const { return norm ? y[i] / ymax : y[i]; }
+  T2_HD float sample(int i) const { return y[i]; }
 };
 
 // mean squared residual, 2-parameter model (run_t2mapping.py:141-147)

@@ -25,6 +25,8 @@
 // n x n system.  Everything is float64, as in the reference.
 #pragma once
 
+#include <type_traits>
+
 #include "t2fit_lane.h"
 
 #if defined(__HIPCC__)
@@ -186,21 +188,24 @@ T2_HD void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy, 
   stp = stpf;
 }
 
-T2_HD void dcsrch(double f, double g, double& stp, double ftol, double gtol, double xtol, double stpmin,
-                  double stpmax, LsState& s) {
+// START call of dcsrch: validates the first step and initialises the search state.
+T2_HD void dcsrch_start(double f, double g, double stp, double ftol, double stpmin, double stpmax, LsState& s) {
+  const double xtrapu = 4.0, p5 = 0.5;
+  if (stp < stpmin || stp > stpmax || g >= 0.0) { s.task = LS_ERROR; return; }
+  s.brackt = false;
+  s.stage = 1;
+  s.finit = f; s.ginit = g; s.gtest = ftol * s.ginit;
+  s.width = stpmax - stpmin; s.width1 = s.width / p5;
+  s.stx = 0.0; s.fx = s.finit; s.gx = s.ginit;
+  s.sty = 0.0; s.fy = s.finit; s.gy = s.ginit;
+  s.stmin = 0.0; s.stmax = stp + xtrapu * stp;
+  s.task = LS_FG;
+}
+
+// Every later call: f, g are the objective and directional derivative at the trial step stp.
+T2_HD void dcsrch(double f, double g, double& stp, double gtol, double xtol, double stpmin, double stpmax,
+                  LsState& s) {
   const double xtrapl = 1.1, xtrapu = 4.0, p5 = 0.5, p66 = 0.66;
-  if (s.task == LS_START) {
-    if (stp < stpmin || stp > stpmax || g >= 0.0) { s.task = LS_ERROR; return; }
-    s.brackt = false;
-    s.stage = 1;
-    s.finit = f; s.ginit = g; s.gtest = ftol * s.ginit;
-    s.width = stpmax - stpmin; s.width1 = s.width / p5;
-    s.stx = 0.0; s.fx = s.finit; s.gx = s.ginit;
-    s.sty = 0.0; s.fy = s.finit; s.gy = s.ginit;
-    s.stmin = 0.0; s.stmax = stp + xtrapu * stp;
-    s.task = LS_FG;
-    return;
-  }
   const double ftest = s.finit + stp * s.gtest;
   if (s.stage == 1 && f <= ftest && g >= 0.0) s.stage = 2;
   int task = LS_FG;
@@ -210,18 +215,25 @@ T2_HD void dcsrch(double f, double g, double& stp, double ftol, double gtol, dou
   if (stp == stpmin && (f > ftest || g >= s.gtest)) task = LS_WARN;     // stp = stpmin
   if (f <= ftest && t2_abs(g) <= gtol * (-s.ginit)) task = LS_CONV;
   if (task != LS_FG) { s.task = task; return; }
-  if (s.stage == 1 && f <= s.fx && f > ftest) {
-    const double fm = f - stp * s.gtest;
-    double fxm = s.fx - s.stx * s.gtest, fym = s.fy - s.sty * s.gtest;
-    const double gm = g - s.gtest;
-    double gxm = s.gx - s.gtest, gym = s.gy - s.gtest;
-    dcstep(s.stx, fxm, gxm, s.sty, fym, gym, stp, fm, gm, s.brackt, s.stmin, s.stmax);
+  // stage 1 works on the modified function psi(stp) = f(stp) - f(0) - ftol*stp*f'(0)
+  const bool modified = s.stage == 1 && f <= s.fx && f > ftest;
+  double fm = f, gm = g, fxm = s.fx, fym = s.fy, gxm = s.gx, gym = s.gy;
+  if (modified) {
+    fm = f - stp * s.gtest;
+    fxm = s.fx - s.stx * s.gtest;
+    fym = s.fy - s.sty * s.gtest;
+    gm = g - s.gtest;
+    gxm = s.gx - s.gtest;
+    gym = s.gy - s.gtest;
+  }
+  dcstep(s.stx, fxm, gxm, s.sty, fym, gym, stp, fm, gm, s.brackt, s.stmin, s.stmax);
+  if (modified) {
     s.fx = fxm + s.stx * s.gtest;
     s.fy = fym + s.sty * s.gtest;
     s.gx = gxm + s.gtest;
     s.gy = gym + s.gtest;
   } else {
-    dcstep(s.stx, s.fx, s.gx, s.sty, s.fy, s.gy, stp, f, g, s.brackt, s.stmin, s.stmax);
+    s.fx = fxm; s.fy = fym; s.gx = gxm; s.gy = gym;
   }
   if (s.brackt) {
     if (t2_abs(s.sty - s.stx) >= p66 * s.width1) stp = s.stx + p5 * (s.sty - s.stx);
@@ -242,26 +254,33 @@ T2_HD void dcsrch(double f, double g, double& stp, double ftol, double gtol, dou
   s.task = LS_FG;
 }
 
-// numpy's float64 add.reduce order for a vector of n < 16 items, fed one item at a time:
-// n < 8 sequential from 0; otherwise ((t0+t1)+(t2+t3)) + ((t4+t5)+(t6+t7)), then t8.. one by one.
-// i and n are wave-uniform, so the switch is a scalar branch on the device.
-struct NpSum16 {
-  double p0, p1, p2, s;
-  T2_HD void add(int i, int n, double t) {
-    if (n < 8) { s = i == 0 ? 0.0 + t : s + t; return; }
-    switch (i) {
-      case 0: p0 = t; break;
-      case 1: p0 += t; break;
-      case 2: p1 = t; break;
-      case 3: p1 += t; p0 += p1; break;
-      case 4: p1 = t; break;
-      case 5: p1 += t; break;
-      case 6: p2 = t; break;
-      case 7: p2 += t; p1 += p2; s = p0 + p1; break;
-      default: s += t; break;
-    }
+// numpy's float64 add.reduce order for a vector of n < 16 items, fed in index order with the index
+// of the first eight items known at compile time: n < 8 is a plain left-to-right sum from 0;
+// otherwise ((t0+t1)+(t2+t3)) + ((t4+t5)+(t6+t7)) and then t8.. one by one.  Both forms are carried
+// (two adds per item) so that no branch on n or on the item index is needed while accumulating.
+struct NpSum {
+  double seq = 0.0, p0 = 0.0, p1 = 0.0, p2 = 0.0, s = 0.0;
+  template <int J> T2_HD void add(double t) {
+    seq = J == 0 ? 0.0 + t : seq + t;
+    if constexpr (J == 0) p0 = t;
+    else if constexpr (J == 1) p0 += t;
+    else if constexpr (J == 2) p1 = t;
+    else if constexpr (J == 3) { p1 += t; p0 += p1; }
+    else if constexpr (J == 4) p1 = t;
+    else if constexpr (J == 5) p1 += t;
+    else if constexpr (J == 6) p2 = t;
+    else { p2 += t; p1 += p2; s = p0 + p1; }
   }
+  T2_HD void tail(double t) { s += t; }
+  T2_HD double total(int n) const { return n < 8 ? seq : s; }
 };
+
+template <int J, int JN, class F> T2_HD void static_for(F&& f) {
+  if constexpr (J < JN) {
+    f(std::integral_constant<int, J>{});
+    static_for<J + 1, JN>(f);
+  }
+}
 
 // ---- the solver -----------------------------------------------------------------------------------
 // Resumable (reverse-communication) form, like the library's own driver loop: the caller evaluates
@@ -323,38 +342,45 @@ struct Lbfgsb {
       }
       return;
     }
-    NpSum16 s0, s1, s2, s3;
-    s0.s = s1.s = s2.s = s3.s = 0.0;
+    // First eight echoes fully unrolled (index known at compile time: straight-line code, the
+    // LDS / scalar loads of all samples and echo times can be issued up front, the summation
+    // order needs no dispatch); echoes 8..15, if any, in a short run-time loop.
+    NpSum s0, s1, s2, s3;
     if constexpr (MODEL == T2FIT_MODEL_GAUSSIAN) {
       const double k = x[0], t2 = x[1], kp = x1[0], t2p = x1[1];
-      for (int i = 0; i < n; ++i) {
+      auto body = [&](int i, auto add) {
         const double y = (double)c.sample(i), te = P.te[i];
         const double E = t2_exp(-te / t2), Ep = t2_exp(-te / t2p);
         const double r0 = y - k * E, r1 = y - kp * E, r2 = y - k * Ep;
-        s0.add(i, n, r0 * r0);
-        s1.add(i, n, r1 * r1);
-        s2.add(i, n, r2 * r2);
-      }
-      f = s0.s / n;
-      g[0] = (s1.s / n - f) / dx[0];
-      g[1] = (s2.s / n - f) / dx[1];
+        add(r0 * r0, r1 * r1, r2 * r2, 0.0);
+      };
+      static_for<0, 8>([&](auto JC) {
+        constexpr int J = decltype(JC)::value;
+        if (J < n) body(J, [&](double a, double b2, double c2, double) { s0.add<J>(a); s1.add<J>(b2); s2.add<J>(c2); });
+      });
+      for (int i = 8; i < n; ++i) body(i, [&](double a, double b2, double c2, double) { s0.tail(a); s1.tail(b2); s2.tail(c2); });
+      f = s0.total(n) / n;
+      g[0] = (s1.total(n) / n - f) / dx[0];
+      g[1] = (s2.total(n) / n - f) / dx[1];
     } else if constexpr (MODEL == T2FIT_MODEL_GAUSSIAN_RICIAN) {
       const double k2 = x[0] * x[0], kp2 = x1[0] * x1[0], t2 = x[1], t2p = x1[1];
       const double sg2 = x[N - 1] * x[N - 1], sgp2 = x1[N - 1] * x1[N - 1];
-      for (int i = 0; i < n; ++i) {
+      auto body = [&](int i, auto add) {
         const double y = (double)c.sample(i), te = P.te[i];
         const double E = t2_exp(-2.0 * te / t2), Ep = t2_exp(-2.0 * te / t2p);
         const double r0 = y - t2_sqrt(k2 * E + sg2), r1 = y - t2_sqrt(kp2 * E + sg2);
         const double r2 = y - t2_sqrt(k2 * Ep + sg2), r3 = y - t2_sqrt(k2 * E + sgp2);
-        s0.add(i, n, r0 * r0);
-        s1.add(i, n, r1 * r1);
-        s2.add(i, n, r2 * r2);
-        s3.add(i, n, r3 * r3);
-      }
-      f = s0.s / n;
-      g[0] = (s1.s / n - f) / dx[0];
-      g[1] = (s2.s / n - f) / dx[1];
-      g[N - 1] = (s3.s / n - f) / dx[N - 1];
+        add(r0 * r0, r1 * r1, r2 * r2, r3 * r3);
+      };
+      static_for<0, 8>([&](auto JC) {
+        constexpr int J = decltype(JC)::value;
+        if (J < n) body(J, [&](double a, double b2, double c2, double d2) { s0.add<J>(a); s1.add<J>(b2); s2.add<J>(c2); s3.add<J>(d2); });
+      });
+      for (int i = 8; i < n; ++i) body(i, [&](double a, double b2, double c2, double d2) { s0.tail(a); s1.tail(b2); s2.tail(c2); s3.tail(d2); });
+      f = s0.total(n) / n;
+      g[0] = (s1.total(n) / n - f) / dx[0];
+      g[1] = (s2.total(n) / n - f) / dx[1];
+      g[N - 1] = (s3.total(n) / n - f) / dx[N - 1];
     } else {
       const double k = x[0], kp = x1[0], t2 = x[1], t2p = x1[1];
       const double sg2 = x[N - 1] * x[N - 1], sgp2 = x1[N - 1] * x1[N - 1];
@@ -367,19 +393,21 @@ struct Lbfgsb {
         const double dd = (xx < 0 ? -xx : xx) + t2_log(t2_i0e(xx));
         return (a - b) + dd;
       };
-      for (int i = 0; i < n; ++i) {
+      auto body = [&](int i, auto add) {
         const float yf = c.sample(i);
         const double te = P.te[i];
         const double E = t2_exp(-te / t2), Ep = t2_exp(-te / t2p);
-        s0.add(i, n, term(k, E, sg2, ls2, yf));
-        s1.add(i, n, term(kp, E, sg2, ls2, yf));
-        s2.add(i, n, term(k, Ep, sg2, ls2, yf));
-        s3.add(i, n, term(k, E, sgp2, lsp2, yf));
-      }
-      f = -s0.s;
-      g[0] = (-s1.s - f) / dx[0];
-      g[1] = (-s2.s - f) / dx[1];
-      g[N - 1] = (-s3.s - f) / dx[N - 1];
+        add(term(k, E, sg2, ls2, yf), term(kp, E, sg2, ls2, yf), term(k, Ep, sg2, ls2, yf), term(k, E, sgp2, lsp2, yf));
+      };
+      static_for<0, 8>([&](auto JC) {
+        constexpr int J = decltype(JC)::value;
+        if (J < n) body(J, [&](double a, double b2, double c2, double d2) { s0.add<J>(a); s1.add<J>(b2); s2.add<J>(c2); s3.add<J>(d2); });
+      });
+      for (int i = 8; i < n; ++i) body(i, [&](double a, double b2, double c2, double d2) { s0.tail(a); s1.tail(b2); s2.tail(c2); s3.tail(d2); });
+      f = -s0.total(n);
+      g[0] = (-s1.total(n) - f) / dx[0];
+      g[1] = (-s2.total(n) - f) / dx[1];
+      g[N - 1] = (-s3.total(n) - f) / dx[N - 1];
     }
   }
 
@@ -398,17 +426,27 @@ struct Lbfgsb {
   T2_HD double& hs(int p, int i) const { return hist[((((head + p) % M) * 2) * N + i) * hstride]; }
   T2_HD double& hy(int p, int i) const { return hist[((((head + p) % M) * 2 + 1) * N + i) * hstride]; }
 
-  // B = theta*I updated by the stored pairs, oldest first.
+  // B = theta*I updated by the stored pairs, oldest first (BFGS recursion; B stays symmetric, so
+  // only the upper triangle is computed).  The next pair is fetched from the ring while the
+  // current one is applied, and the two scalings are reciprocals applied by multiplication: at one
+  // wave per SIMD this block is latency-bound, and 18 IEEE divisions per pair dominated it.
   T2_HD void build_b(double (*B)[N]) const {
     T2_UNROLL
     for (int i = 0; i < N; ++i)
       T2_UNROLL
       for (int j = 0; j < N; ++j) B[i][j] = i == j ? theta : 0.0;
-    for (int p = 0; p < col; ++p) {
-      double sp[N], yp[N], bs[N];
-      double sbs = 0.0, ys = 0.0;
+    double sp[N], yp[N];
+    if (col > 0) {
       T2_UNROLL
-      for (int i = 0; i < N; ++i) { sp[i] = hs(p, i); yp[i] = hy(p, i); }
+      for (int i = 0; i < N; ++i) { sp[i] = hs(0, i); yp[i] = hy(0, i); }
+    }
+    for (int p = 0; p < col; ++p) {
+      double sn[N], yn[N];
+      const int pn = p + 1 < col ? p + 1 : p;
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) { sn[i] = hs(pn, i); yn[i] = hy(pn, i); }
+      double bs[N];
+      double sbs = 0.0, ys = 0.0;
       T2_UNROLL
       for (int i = 0; i < N; ++i) {
         double a = 0.0;
@@ -418,10 +456,20 @@ struct Lbfgsb {
       }
       T2_UNROLL
       for (int i = 0; i < N; ++i) { sbs += sp[i] * bs[i]; ys += yp[i] * sp[i]; }
+      const double rys = 1.0 / ys, rsbs = 1.0 / sbs;
+      double ty[N], tb[N];
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) { ty[i] = yp[i] * rys; tb[i] = bs[i] * rsbs; }
       T2_UNROLL
       for (int i = 0; i < N; ++i)
         T2_UNROLL
-        for (int j = 0; j < N; ++j) B[i][j] += yp[i] * yp[j] / ys - bs[i] * bs[j] / sbs;
+        for (int j = i; j < N; ++j) {
+          const double v = B[i][j] + (yp[i] * ty[j] - bs[i] * tb[j]);
+          B[i][j] = v;
+          B[j][i] = v;
+        }
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) { sp[i] = sn[i]; yp[i] = yn[i]; }
     }
   }
 
@@ -607,7 +655,7 @@ struct Lbfgsb {
 
   // Start a fit: x = x0 clipped into the box (scipy), empty memory.  Next: eval(), then advance().
   // `hist_` must hold 2*M*N doubles at stride `hstride_`.
-  T2_HD void init(const LaneParams& P, const double* lb_, const double* ub_, double* hist_, int hstride_) {
+  T2_HD void init(const double* x0_, const double* lb_, const double* ub_, double* hist_, int hstride_) {
     hist = hist_;
     hstride = hstride_;
     head = 0;
@@ -615,7 +663,7 @@ struct Lbfgsb {
     for (int i = 0; i < N; ++i) {
       lb[i] = lb_[i];
       ub[i] = ub_[i];
-      x[i] = t2_clip(P.x0[i], lb[i], ub[i]);
+      x[i] = t2_clip(x0_[i], lb[i], ub[i]);
       iwhere[i] = (ub[i] - lb[i] <= 0.0) ? 3 : 0;
     }
     col = 0; nit = 0; nfev = 0; ifun = 0;
@@ -624,21 +672,85 @@ struct Lbfgsb {
     first = true;
   }
 
-  // Line search could not be completed: back to the previous iterate.  With an empty memory that is
-  // scipy's ABNORMAL termination (success False); otherwise drop the memory and redo the iteration.
-  T2_HD bool line_search_failed(const LaneParams& P) {
-    T2_UNROLL
-    for (int i = 0; i < N; ++i) { x[i] = t[i]; g[i] = r[i]; }
-    f = fold;
-    if (col == 0) return true;
-    col = 0; theta = 1.0;
-    return begin_iteration(P);
-  }
-
-  // Cauchy point, subspace minimisation, line-search set-up and its first trial point.
-  // Returns true if the fit ended, false if `x` now holds a point to evaluate.
-  T2_HD bool begin_iteration(const LaneParams& P) {
+  // Everything between two evaluations.  Control is arranged so that each expensive block (the
+  // end-of-iteration bookkeeping and the begin-iteration work: B, Cauchy point, subspace step,
+  // line-search set-up) exists exactly once in the instruction stream, so the lanes of a wave that
+  // sit in different phases serialise over little code.  Returns true when the fit has ended,
+  // false when `x` holds the next point to evaluate.
+  T2_HD bool advance(const ObjCtx& c) {
+    const LaneParams& P = *c.P;
+    const double epsmch = 2.220446049250313e-16;
+    enum { GO_BEGIN, GO_TRIAL, GO_FAIL, GO_DONE };
+    int next;
+    // ---- 1. digest the evaluation that just finished ----
+    if (first) {
+      first = false;
+      sbgnrm = projgr(x, g);
+      next = GO_BEGIN;
+      if (sbgnrm <= P.gtol) { status = T2FIT_ST_CONVERGED; next = GO_DONE; }
+    } else {
+      gd = 0.0;
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) gd += g[i] * d[i];
+      dcsrch(f, gd, stp, 0.9, 0.1, 0.0, stpmx, ls);
+      if (ls.task == LS_FG) {
+        ++ifun;
+        next = ifun - 1 >= P.maxls ? GO_FAIL : GO_TRIAL;
+      } else {
+        // ---- new iterate: stop tests, then the correction pair ----
+        ++nit;
+#if !defined(__HIP_DEVICE_COMPILE__)
+        if (c.trace && *c.trace_n < c.trace_cap) {
+          double* tr = c.trace + 4 * (*c.trace_n)++;
+          tr[0] = x[0]; tr[1] = x[1]; tr[2] = N == 3 ? x[N - 1] : 0.0; tr[3] = f;
+        }
+#endif
+        sbgnrm = projgr(x, g);
+        const double tol = (P.ftol / epsmch) * epsmch;  // factr * epsmch
+        if (nit >= P.maxiter || nfev > P.maxfun) {
+          next = GO_DONE;  // scipy: STOP, success False
+        } else if (sbgnrm <= P.gtol || (fold - f) <= tol * t2_max3(t2_abs(fold), t2_abs(f), 1.0)) {
+          status = T2FIT_ST_CONVERGED;
+          next = GO_DONE;
+        } else {
+          double rr = 0.0, dr, ddum;
+          T2_UNROLL
+          for (int i = 0; i < N; ++i) { r[i] = g[i] - r[i]; rr += r[i] * r[i]; }
+          if (stp == 1.0) {
+            dr = gd - gdold;
+            ddum = -gdold;
+          } else {
+            dr = (gd - gdold) * stp;
+            T2_UNROLL
+            for (int i = 0; i < N; ++i) d[i] *= stp;
+            ddum = -gdold * stp;
+          }
+          if (!(dr <= epsmch * ddum)) {  // else: curvature too small, skip the update
+            if (col == M) {  // ring is full: the oldest pair is dropped
+              head = (head + 1) % M;
+              col = M - 1;
+            }
+            T2_UNROLL
+            for (int i = 0; i < N; ++i) { hs(col, i) = d[i]; hy(col, i) = r[i]; }
+            ++col;
+            theta = rr / dr;
+          }
+          next = GO_BEGIN;
+        }
+      }
+    }
+    // ---- 2. (re)start iterations until one yields a trial point or the fit ends ----
     for (;;) {
+      if (next == GO_FAIL) {
+        // line search could not be completed: back to the previous iterate.  With an empty memory
+        // that is scipy's ABNORMAL termination (success False); otherwise drop the memory and redo.
+        T2_UNROLL
+        for (int i = 0; i < N; ++i) { x[i] = t[i]; g[i] = r[i]; }
+        f = fold;
+        next = GO_DONE;
+        if (col != 0) { col = 0; theta = 1.0; next = GO_BEGIN; }
+      }
+      if (next != GO_BEGIN) break;
       double B[N][N];
       build_b(B);
       cauchy(x, g, B, theta, sbgnrm, iwhere, z);
@@ -651,7 +763,7 @@ struct Lbfgsb {
           continue;
         }
       }
-      // ---- line search along d = z - x (lnsrlb) ----
+      // line search along d = z - x (lnsrlb)
       T2_UNROLL
       for (int i = 0; i < N; ++i) { d[i] = z[i] - x[i]; t[i] = x[i]; r[i] = g[i]; }
       stpmx = 1e10;
@@ -674,92 +786,20 @@ struct Lbfgsb {
       }
       stp = 1.0;  // every variable is boxed, so the first step is not rescaled by 1/|d|
       fold = f;
-      ifun = 0;
-      ls.task = LS_START;
       gd = 0.0;
       T2_UNROLL
       for (int i = 0; i < N; ++i) gd += g[i] * d[i];
       gdold = gd;
-      bool fail = gd >= 0.0;  // not a descent direction
-      if (!fail) {
-        dcsrch(f, gd, stp, 1e-3, 0.9, 0.1, 0.0, stpmx, ls);
-        fail = ls.task != LS_FG;  // START can only answer FG or ERROR
-      }
-      if (!fail) {
-        ifun = 1;
-        fail = ifun - 1 >= P.maxls;
-      }
-      if (fail) {
-        // x, f, g are still the previous iterate here
-        if (col == 0) return true;
-        col = 0; theta = 1.0;
-        continue;
-      }
+      dcsrch_start(f, gd, stp, 1e-3, 0.0, stpmx, ls);  // ERROR also covers gd >= 0: not a descent direction
+      ifun = 1;
+      next = (ls.task != LS_FG || ifun - 1 >= P.maxls) ? GO_FAIL : GO_TRIAL;
+    }
+    if (next == GO_TRIAL) {
       T2_UNROLL
       for (int i = 0; i < N; ++i) x[i] = stp == 1.0 ? z[i] : stp * d[i] + t[i];
       return false;
     }
-  }
-
-  // A trial point of the line search has been evaluated.
-  T2_HD bool advance(const ObjCtx& c) {
-    const LaneParams& P = *c.P;
-    const double epsmch = 2.220446049250313e-16;
-    if (first) {
-      first = false;
-      sbgnrm = projgr(x, g);
-      if (sbgnrm <= P.gtol) { status = T2FIT_ST_CONVERGED; return true; }
-      return begin_iteration(P);
-    }
-    gd = 0.0;
-    T2_UNROLL
-    for (int i = 0; i < N; ++i) gd += g[i] * d[i];
-    dcsrch(f, gd, stp, 1e-3, 0.9, 0.1, 0.0, stpmx, ls);
-    if (ls.task == LS_ERROR) return line_search_failed(P);
-    if (ls.task == LS_FG) {
-      ++ifun;
-      if (ifun - 1 >= P.maxls) return line_search_failed(P);
-      T2_UNROLL
-      for (int i = 0; i < N; ++i) x[i] = stp == 1.0 ? z[i] : stp * d[i] + t[i];
-      return false;
-    }
-    // ---- new iterate ----
-    ++nit;
-#if !defined(__HIP_DEVICE_COMPILE__)
-    if (c.trace && *c.trace_n < c.trace_cap) {
-      double* tr = c.trace + 4 * (*c.trace_n)++;
-      tr[0] = x[0]; tr[1] = x[1]; tr[2] = N == 3 ? x[N - 1] : 0.0; tr[3] = f;
-    }
-#endif
-    sbgnrm = projgr(x, g);
-    if (nit >= P.maxiter || nfev > P.maxfun) return true;  // scipy: STOP, success False
-    if (sbgnrm <= P.gtol) { status = T2FIT_ST_CONVERGED; return true; }
-    const double tol = (P.ftol / epsmch) * epsmch;  // factr * epsmch
-    if ((fold - f) <= tol * t2_max3(t2_abs(fold), t2_abs(f), 1.0)) { status = T2FIT_ST_CONVERGED; return true; }
-    // ---- correction pair ----
-    double rr = 0.0, dr, ddum;
-    T2_UNROLL
-    for (int i = 0; i < N; ++i) { r[i] = g[i] - r[i]; rr += r[i] * r[i]; }
-    if (stp == 1.0) {
-      dr = gd - gdold;
-      ddum = -gdold;
-    } else {
-      dr = (gd - gdold) * stp;
-      T2_UNROLL
-      for (int i = 0; i < N; ++i) d[i] *= stp;
-      ddum = -gdold * stp;
-    }
-    if (!(dr <= epsmch * ddum)) {  // else: curvature too small, skip the update
-      if (col == M) {  // ring is full: the oldest pair is dropped
-        head = (head + 1) % M;
-        col = M - 1;
-      }
-      T2_UNROLL
-      for (int i = 0; i < N; ++i) { hs(col, i) = d[i]; hy(col, i) = r[i]; }
-      ++col;
-      theta = rr / dr;
-    }
-    return begin_iteration(P);
+    return true;
   }
 
   T2_HD void result(LaneResult& out) const {
@@ -778,7 +818,7 @@ template <int MODEL>
 T2_HD void lbfgsb_solve(const ObjCtx& c, const double* lb, const double* ub, LaneResult& out) {
   Lbfgsb<MODEL> s;
   double hist[2 * Lbfgsb<MODEL>::M * Lbfgsb<MODEL>::N];
-  s.init(*c.P, lb, ub, hist, 1);
+  s.init(c.P->x0, lb, ub, hist, 1);
   do {
     s.eval(c);
   } while (!s.advance(c));

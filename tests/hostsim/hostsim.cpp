@@ -21,11 +21,15 @@ extern "C" int hostsim_fit_rows(const t2fit_config* cfg, const float* rows, int6
   if (rc != T2FIT_OK) return rc;
   const LaneParams P = make_lane_params(*cfg);
   for (int64_t v = 0; v < n; ++v) {
-    EchoView y{rows + v * cfg->n_te, 1};
+    float buf[T2FIT_MAX_TE];
+    for (int i = 0; i < cfg->n_te; ++i) buf[i] = rows[v * cfg->n_te + i];
+    bool finite;
+    float y0_raw;
+    const ObjCtx c = prepare_samples(P, buf, 1, finite, y0_raw);
     LaneResult r;
-    fit_lane(P, y, r);
+    fit_lane(P, c, finite, y0_raw, r);
     LaneOutputs o;
-    lane_epilogue(P, y, r, o, r2 != nullptr);
+    lane_epilogue(c, r, o, r2 != nullptr);
     for (int j = 0; j < 3; ++j) x[v * 3 + j] = r.x[j];
     fun[v] = r.fun;
     nit[v] = r.nit;
@@ -44,13 +48,15 @@ extern "C" int hostsim_trace_row(const t2fit_config* cfg, const float* row, doub
   int rc = config_check(cfg, &why);
   if (rc != T2FIT_OK) return rc;
   const LaneParams P = make_lane_params(*cfg);
-  EchoView y{row, 1};
+  float buf[T2FIT_MAX_TE];
+  for (int i = 0; i < cfg->n_te; ++i) buf[i] = row[i];
   bool finite;
-  ObjCtx c = make_ctx(P, y, finite);
+  float y0_raw;
+  ObjCtx c = prepare_samples(P, buf, 1, finite, y0_raw);
   *n_out = 0;
   c.trace = trace; c.trace_cap = cap; c.trace_n = n_out;
   double lb[3], ub[3];
-  if (!lane_bounds(P, y[0], lb, ub) || !finite) return -10;
+  if (!lane_bounds(P, y0_raw, lb, ub) || !finite) return -10;
   LaneResult r;
   if (P.model == T2FIT_MODEL_GAUSSIAN) lbfgsb_solve<T2FIT_MODEL_GAUSSIAN>(c, lb, ub, r);
   else if (P.model == T2FIT_MODEL_GAUSSIAN_RICIAN) lbfgsb_solve<T2FIT_MODEL_GAUSSIAN_RICIAN>(c, lb, ub, r);
@@ -65,9 +71,11 @@ extern "C" int hostsim_residuals(const t2fit_config* cfg, const float* rows, int
                                  const float* t2, const float* sigma, float* res) {
   const LaneParams P = make_lane_params(*cfg);
   for (int64_t v = 0; v < n; ++v) {
-    EchoView y{rows + v * cfg->n_te, 1};
+    float buf[T2FIT_MAX_TE];
+    for (int i = 0; i < cfg->n_te; ++i) buf[i] = rows[v * cfg->n_te + i];
     bool finite;
-    const ObjCtx c = make_ctx(P, y, finite);
+    float y0_raw;
+    const ObjCtx c = prepare_samples(P, buf, 1, finite, y0_raw);
     res[v] = residual_mean(c, k[v], t2[v], sigma[v]);
   }
   return 0;
