@@ -27,6 +27,8 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kLdsStride = kBlock + 1;
+bool g_use_persistent = true;  // LM: false selects the one-voxel-per-lane kernel (T2FIT_ONE_SHOT=1)
+int g_refill_min = 0;           // > 0 overrides the per-solver refill batch (T2FIT_REFILL_MIN)
 int g_persistent_blocks = 2048;  // grid of the persistent kernel (T2FIT_PERSISTENT_BLOCKS overrides)
 
 thread_local std::string g_err;
@@ -147,25 +149,45 @@ __global__ __launch_bounds__(kBlock) void fit_volume_kernel(const LaneParams P, 
 constexpr int kChunk = 256;
 constexpr int kQueueCap = 64 + kChunk;
 
-template <int MODEL>
-__global__ __launch_bounds__(kBlock) void fit_lbfgsb_persistent_kernel(const LaneParams P,
+// what the persistent kernel needs to know about a resumable lane solver
+template <int MODEL> struct LbfgsbLane {
+  using Solver = Lbfgsb<MODEL>;
+  static constexpr int NP = Solver::N;
+  static constexpr int kHistDoubles = 2 * Solver::M * Solver::N;  // correction pairs, per lane, in LDS
+  static constexpr int kRefillMin = 8;   // measured on MI355X: 1 -> 28.1 ms, 8 -> 26.8 ms, 16 -> 27.6 ms
+  __device__ static void init(Solver& s, const ObjCtx&, const double* x0, const double* lb, const double* ub,
+                              double* hist) { s.init(x0, lb, ub, hist, kBlock); }
+  __device__ static void result(const Solver& s, const ObjCtx&, LaneResult& r) { s.result(r); }
+};
+template <typename T, int NPAR> struct LmLaneAdaptor {
+  using Solver = LmLane<T, NPAR>;
+  static constexpr int NP = NPAR;
+  static constexpr int kHistDoubles = 0;
+  static constexpr int kRefillMin = 16;  // measured (f32, 3 parameters): 1 -> 2.36 ms, 16 -> 1.92 ms, 32 -> 1.98 ms
+  __device__ static void init(Solver& s, const ObjCtx& c, const double* x0, const double* lb, const double* ub,
+                              double*) { s.init(c, x0, lb, ub); }
+  __device__ static void result(const Solver& s, const ObjCtx& c, LaneResult& r) { s.result(c, r); }
+};
+
+template <class A>
+__global__ __launch_bounds__(kBlock) void fit_persistent_kernel(const LaneParams P,
                                                                        const float* __restrict__ echoes, int layout,
                                                                        const uint8_t* __restrict__ mask, int64_t n_vox,
-                                                                       DevMaps m, unsigned long long* next_chunk) {
+                                                                       DevMaps m, unsigned long long* next_chunk, int refill_min) {
   extern __shared__ float lds[];
-  constexpr int NP = MODEL == T2FIT_MODEL_GAUSSIAN ? 2 : 3;
+  constexpr int NP = A::NP;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* col = lds + threadIdx.x;
-  // LDS: [n_te][257] float sample columns | [2*M*N][256] double correction pairs | 4 queues
+  // LDS: [n_te][257] float sample columns | [kHistDoubles][256] double solver history | 4 queues
   double* hist = reinterpret_cast<double*>(lds + ((P.n_te * kLdsStride + 1) & ~1)) + threadIdx.x;
-  uint32_t* queue = reinterpret_cast<uint32_t*>(hist - threadIdx.x + 2 * Lbfgsb<MODEL>::M * NP * kBlock) + wave * kQueueCap;
+  uint32_t* queue = reinterpret_cast<uint32_t*>(hist - threadIdx.x + A::kHistDoubles * kBlock) + wave * kQueueCap;
   const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const EchoView y{col, kLdsStride};
   int q_head = 0, q_count = 0;
   bool chunks_left = true;
   bool busy = false;
   int64_t v = 0;
-  Lbfgsb<MODEL> s;
+  typename A::Solver s;
   ObjCtx c;
   c.P = &P;
   c.y = y;
@@ -174,8 +196,10 @@ __global__ __launch_bounds__(kBlock) void fit_lbfgsb_persistent_kernel(const Lan
 #pragma unroll
   for (int j = 0; j < 3; ++j) { box_x0[j] = P.x0[j]; box_lb[j] = P.lb[j]; box_ub[j] = P.ub[j]; }
   for (;;) {
+    // Refill in batches: the refill path (sample loads, seed / set-up) runs with only the idle lanes
+    // active, so it is entered when at least refill_min lanes are idle (or nothing is running).
     const unsigned long long need = __ballot(!busy);
-    if (need) {
+    if (__popcll(need) >= refill_min || need == ~0ull) {
       const int n_need = __popcll(need);
       while (q_count < n_need && chunks_left) {
         unsigned long long cidx = 0;
@@ -270,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void fit_lbfgsb_persistent_kernel(const Lan
           store_fit(m, v, r);
           busy = false;
         } else {
-          s.init(box_x0, lb, ub, hist, kBlock);
+          A::init(s, c, box_x0, lb, ub, hist);
         }
       }
     }
@@ -282,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void fit_lbfgsb_persistent_kernel(const Lan
       s.eval(c);
       if (s.advance(c)) {
         LaneResult r;
-        s.result(r);
+        A::result(s, c, r);
         store_fit(m, v, r);
         busy = false;
       }
@@ -424,16 +448,20 @@ FitKernel pick_kernel(const t2fit_config& c) {
   return nullptr;  // the L-BFGS-B solver runs in the persistent kernel
 }
 
-template <int MODEL>
-hipError_t launch_persistent(unsigned grid, size_t lds, hipStream_t st, const LaneParams& P, const float* echoes,
-                             int layout, const uint8_t* mask, int64_t n_vox, const DevMaps& dm,
+template <class A>
+hipError_t launch_persistent(unsigned grid, size_t lds_samples, hipStream_t st, const LaneParams& P,
+                             const float* echoes, int layout, const uint8_t* mask, int64_t n_vox, const DevMaps& dm,
                              unsigned long long* counter) {
-  auto kern = fit_lbfgsb_persistent_kernel<MODEL>;
+  auto kern = fit_persistent_kernel<A>;
+  const size_t lds = ((lds_samples / sizeof(float) + 1) & ~(size_t)1) * sizeof(float) +
+                     (size_t)A::kHistDoubles * kBlock * sizeof(double) +
+                     (size_t)(kBlock / 64) * kQueueCap * sizeof(uint32_t);
   // > 64 KiB of dynamic LDS (the correction pairs of 256 lanes) has to be opted into
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox, dm, counter);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox, dm, counter,
+                     g_refill_min > 0 ? g_refill_min : A::kRefillMin);
   return hipGetLastError();
 }
 
@@ -451,11 +479,18 @@ int check_common(const t2fit_config* cfg, const void* echoes, int layout, int64_
 int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const uint8_t* mask, int64_t n_vox,
                const DevMaps& dm, hipStream_t st) {
   if (n_vox == 0) return T2FIT_OK;
+  static const bool env_read = [] {  // tuning / A-B switches, read once
+    if (const char* e = std::getenv("T2FIT_ONE_SHOT")) g_use_persistent = std::atoi(e) == 0;
+    if (const char* e = std::getenv("T2FIT_PERSISTENT_BLOCKS")) g_persistent_blocks = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("T2FIT_REFILL_MIN")) g_refill_min = std::min(64, std::max(1, std::atoi(e)));
+    return true;
+  }();
+  (void)env_read;
   const LaneParams P = make_lane_params(*cfg);
   const unsigned grid = (unsigned)((n_vox + kBlock - 1) / kBlock);
   const size_t lds = (size_t)cfg->n_te * kLdsStride * sizeof(float);
   FitKernel kern = pick_kernel(*cfg);
-  const bool persistent = cfg->solver == T2FIT_SOLVER_LBFGSB;
+  const bool persistent = g_use_persistent || cfg->solver == T2FIT_SOLVER_LBFGSB;
   if (persistent && n_vox >= 0xffffffffLL) return fail(T2FIT_E_INVALID, "n_vox must be below 2^32 per call");
   unsigned long long* counter = nullptr;
   if (persistent) {
@@ -473,20 +508,20 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
     // one workgroup per CU slot; not required to be co-resident (work comes from an atomic queue)
     const int64_t chunks = (n_vox + kChunk - 1) / kChunk;
     const unsigned pgrid = (unsigned)std::min<int64_t>((chunks + 3) / 4, g_persistent_blocks);
-    const int np = cfg->model == T2FIT_MODEL_GAUSSIAN ? 2 : 3;
-    const size_t plds = (((size_t)cfg->n_te * kLdsStride + 1) & ~(size_t)1) * sizeof(float) +
-                        (size_t)2 * 10 * np * kBlock * sizeof(double) + (size_t)(kBlock / 64) * kQueueCap * sizeof(uint32_t);
     hipError_t pe;
-    switch (cfg->model) {
-      case T2FIT_MODEL_GAUSSIAN:
-        pe = launch_persistent<T2FIT_MODEL_GAUSSIAN>(pgrid, plds, st, P, echoes, layout, mask, n_vox, dm, counter);
-        break;
-      case T2FIT_MODEL_GAUSSIAN_RICIAN:
-        pe = launch_persistent<T2FIT_MODEL_GAUSSIAN_RICIAN>(pgrid, plds, st, P, echoes, layout, mask, n_vox, dm, counter);
-        break;
-      default:
-        pe = launch_persistent<T2FIT_MODEL_RICIAN>(pgrid, plds, st, P, echoes, layout, mask, n_vox, dm, counter);
+#define T2_PERSIST(...) pe = launch_persistent<__VA_ARGS__>(pgrid, lds, st, P, echoes, layout, mask, n_vox, dm, counter)
+    if (cfg->solver == T2FIT_SOLVER_LBFGSB) {
+      if (cfg->model == T2FIT_MODEL_GAUSSIAN) T2_PERSIST(LbfgsbLane<T2FIT_MODEL_GAUSSIAN>);
+      else if (cfg->model == T2FIT_MODEL_GAUSSIAN_RICIAN) T2_PERSIST(LbfgsbLane<T2FIT_MODEL_GAUSSIAN_RICIAN>);
+      else T2_PERSIST(LbfgsbLane<T2FIT_MODEL_RICIAN>);
+    } else if (cfg->precision == T2FIT_PREC_F32) {
+      if (cfg->model == T2FIT_MODEL_GAUSSIAN) T2_PERSIST(LmLaneAdaptor<float, 2>);
+      else T2_PERSIST(LmLaneAdaptor<float, 3>);
+    } else {
+      if (cfg->model == T2FIT_MODEL_GAUSSIAN) T2_PERSIST(LmLaneAdaptor<double, 2>);
+      else T2_PERSIST(LmLaneAdaptor<double, 3>);
     }
+#undef T2_PERSIST
     if (pe != hipSuccess) return fail(T2FIT_E_HIP, std::string("persistent fit launch: ") + hipGetErrorString(pe));
     if (g_timing) {  // the timed kernel is the fit; the epilogue pass is a separate, HBM-bound launch
       T2_HIP(hipEventRecord(g_ev1, st));
@@ -680,6 +715,13 @@ int t2fit_residuals_dev(const t2fit_config* cfg, const float* echoes_dev, int la
   if (rc != T2FIT_OK) return rc;
   if (!t2 || !k || !res) return fail(T2FIT_E_INVALID, "t2/k/res must be non-NULL");
   if (n_vox == 0) return T2FIT_OK;
+  static const bool env_read = [] {  // tuning / A-B switches, read once
+    if (const char* e = std::getenv("T2FIT_ONE_SHOT")) g_use_persistent = std::atoi(e) == 0;
+    if (const char* e = std::getenv("T2FIT_PERSISTENT_BLOCKS")) g_persistent_blocks = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("T2FIT_REFILL_MIN")) g_refill_min = std::min(64, std::max(1, std::atoi(e)));
+    return true;
+  }();
+  (void)env_read;
   const LaneParams P = make_lane_params(*cfg);
   const unsigned grid = (unsigned)((n_vox + kBlock - 1) / kBlock);
   const size_t lds = (size_t)cfg->n_te * kLdsStride * sizeof(float);

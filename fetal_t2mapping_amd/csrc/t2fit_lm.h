@@ -20,14 +20,17 @@ template <typename T> struct LmEval {
   T g[3];   // J^T r  (descent step solves (A + lambda D) d = g)
 };
 
-// Residuals and model Jacobian at q = (k, R, s).  NP = 2: m = k E;  NP = 3: m = sqrt(k^2 E^2 + s^2).
+// Residuals and model Jacobian at q.  NP = 2: q = (k, R), m = k E with E = exp(-t R), R = 1/T2.
+// NP = 3: q = (a, R, u) = (k^2, 1/T2, sigma^2), m = sqrt(a E^2 + u): m^2 is linear in (a, u), which
+// removes the flat, badly scaled sigma direction the (k, T2, sigma) form has when sigma << k E
+// (d m / d sigma = sigma / m -> 0) and halves the number of iterations.  The model is even in k and
+// sigma, so squaring loses nothing; the box maps monotonically.
 template <typename T, int NP>
 T2_HD void lm_eval(const ObjCtx& c, const T* q, LmEval<T>& e) {
   const LaneParams& P = *c.P;
   const int n = P.n_te;
   const T k = q[0], R = q[1], s = (NP == 3) ? q[2] : T(0);
   T f = 0, akk = 0, akr = 0, aks = 0, arr = 0, ars = 0, ass = 0, gk = 0, gr = 0, gs = 0;
-  const T k2 = k * k, s2 = s * s;
   for (int i = 0; i < n; ++i) {
     const T t = TeOf<T>::at(P, i);
     const T y = (T)c.sample(i);
@@ -39,12 +42,12 @@ T2_HD void lm_eval(const ObjCtx& c, const T* q, LmEval<T>& e) {
       jr = -t * m;
     } else {
       const T E2 = t2_exp(T(-2) * t * R);
-      const T v = k2 * E2 + s2;
+      const T v = k * E2 + s;
       const T rm = t2_rsqrt(v);
       m = v * rm;
-      jk = k * E2 * rm;
-      jr = -t * k * jk;
-      js = s * rm;
+      js = T(0.5) * rm;
+      jk = E2 * js;
+      jr = T(-2) * t * k * jk;
     }
     const T r = y - m;
     f += r * r;
@@ -93,8 +96,8 @@ T2_HD void lm_step(const LmEval<T>& e, T lambda, const bool* fixed, T* d) {
 }
 
 template <typename T> struct LmTol;
-template <> struct LmTol<double> { static constexpr double xtol = 1e-10, ftiny = 1e-15; };
-template <> struct LmTol<float> { static constexpr float xtol = 2e-6f, ftiny = 1e-7f; };
+template <> struct LmTol<double> { static constexpr double xtol = 1e-6, ftiny = 1e-12; };
+template <> struct LmTol<float> { static constexpr float xtol = 1e-5f, ftiny = 1e-6f; };
 
 // Weighted log-linear regression ln y = ln k - R t with weights y^2 (matches the least-squares
 // objective to first order).  Returns false if fewer than two positive samples.
@@ -121,61 +124,53 @@ T2_HD bool loglinear_seed(const ObjCtx& c, T& k, T& R) {
   return t2_finite(k) && t2_finite(R);
 }
 
+// Resumable form (same protocol as Lbfgsb): init() seeds the fit, eval() evaluates residuals and
+// Jacobian at the pending point, advance() accepts or rejects it and proposes the next one.
 template <typename T, int NP>
-T2_HD void lm_solve(const ObjCtx& c, const double* lbd, const double* ubd, LaneResult& out) {
-  const LaneParams& P = *c.P;
-  const int n = P.n_te;
-  // bounds in (k, R, s); R = 1/T2 reverses the T2 interval
-  T lo[3], hi[3];
-  lo[0] = (T)lbd[0]; hi[0] = (T)ubd[0];
-  lo[1] = (T)(1.0 / ubd[1]); hi[1] = (T)(1.0 / lbd[1]);
-  lo[2] = (T)lbd[2]; hi[2] = (T)ubd[2];
-  T q[3];
-  q[0] = t2_clip((T)P.x0[0], lo[0], hi[0]);
-  q[1] = t2_clip((T)(1.0 / P.x0[1]), lo[1], hi[1]);
-  q[2] = (NP == 3) ? t2_clip((T)P.x0[2], lo[2], hi[2]) : T(0);
-  {
+struct LmLane {
+  T lo[3], hi[3];        // box in (k | k^2, R, sigma^2)
+  T q[3], qn[3], d[3];   // accepted point, pending point, step that led to it
+  LmEval<T> e, en;
+  T lambda, nu, rel, pred, xtol;
+  double lbd[3], ubd[3];
+  int it, maxit;
+  uint8_t status;
+  bool first;
+
+  T2_HD void init(const ObjCtx& c, const double* x0, const double* lb_, const double* ub_) {
+    const LaneParams& P = *c.P;
+    auto sq = [](double v) { return v > 0.0 ? v * v : 0.0; };  // |.| >= 0 side of an even parameter
+    for (int j = 0; j < 3; ++j) { lbd[j] = lb_[j]; ubd[j] = ub_[j]; }
+    lo[0] = NP == 3 ? (T)sq(lbd[0]) : (T)lbd[0];
+    hi[0] = NP == 3 ? (T)sq(ubd[0]) : (T)ubd[0];
+    lo[1] = (T)(1.0 / ubd[1]); hi[1] = (T)(1.0 / lbd[1]);  // R = 1/T2 reverses the interval
+    lo[2] = (T)sq(lbd[2]); hi[2] = (T)sq(ubd[2]);
+    qn[0] = t2_clip(NP == 3 ? (T)sq(x0[0]) : (T)x0[0], lo[0], hi[0]);
+    qn[1] = t2_clip((T)(1.0 / x0[1]), lo[1], hi[1]);
+    qn[2] = (NP == 3) ? t2_clip((T)sq(x0[2]), lo[2], hi[2]) : T(0);
     T ks, Rs;
     if (loglinear_seed<T>(c, ks, Rs)) {
-      q[0] = t2_clip(ks, lo[0], hi[0]);
-      q[1] = t2_clip(Rs, lo[1], hi[1]);
+      qn[0] = t2_clip(NP == 3 ? ks * ks : ks, lo[0], hi[0]);
+      qn[1] = t2_clip(Rs, lo[1], hi[1]);
     }
+    xtol = P.lm_xtol > 0 ? (T)P.lm_xtol : (T)LmTol<T>::xtol;
+    lambda = T(1e-3);
+    nu = T(2);
+    it = 0;
+    maxit = P.maxiter > 0 ? P.maxiter : 60;
+    status = T2FIT_ST_NOT_CONV;
+    first = true;
   }
-  LmEval<T> e;
-  lm_eval<T, NP>(c, q, e);
-  const T xtol = P.lm_xtol > 0 ? (T)P.lm_xtol : (T)LmTol<T>::xtol;
-  T lambda = T(1e-3), nu = T(2);
-  int it = 0;
-  uint8_t status = T2FIT_ST_NOT_CONV;
-  const int maxit = P.maxiter > 0 ? P.maxiter : 60;
-  if (!t2_finite(e.f)) {
-    status = T2FIT_ST_NONFINITE;
-  } else {
-    for (; it < maxit; ++it) {
-      bool fixed[3];
-      for (int j = 0; j < 3; ++j)
-        fixed[j] = (q[j] <= lo[j] && e.g[j] < T(0)) || (q[j] >= hi[j] && e.g[j] > T(0));
-      T d[3];
-      lm_step<T, NP>(e, lambda, fixed, d);
-      T qn[3];
-      bool moved = false;
-      T rel = 0;
-      for (int j = 0; j < 3; ++j) {
-        qn[j] = t2_clip(q[j] + d[j], lo[j], hi[j]);
-        if (j >= NP) qn[j] = 0;
-        const T dj = qn[j] - q[j];
-        moved = moved || dj != T(0);
-        rel = t2_max(rel, t2_abs(dj) / (t2_abs(q[j]) + (j == 1 ? T(1e-6) : T(1e-3))));
-      }
-      if (!moved) { status = T2FIT_ST_CONVERGED; break; }
-      LmEval<T> en;
-      lm_eval<T, NP>(c, qn, en);
-      // predicted reduction of the (unclipped) damped model: d^T (lambda D d + g)
-      T pred = 0;
-      {
-        const T dd[3] = {e.a[0], e.a[3], e.a[5]};
-        for (int j = 0; j < NP; ++j) pred += d[j] * (lambda * t2_max(dd[j], T(1e-30)) * d[j] + e.g[j]);
-      }
+
+  T2_HD void eval(const ObjCtx& c) { lm_eval<T, NP>(c, qn, en); }
+
+  T2_HD bool advance(const ObjCtx& c) {
+    if (first) {
+      first = false;
+      for (int j = 0; j < 3; ++j) q[j] = qn[j];
+      e = en;
+      if (!t2_finite(e.f)) { status = T2FIT_ST_NONFINITE; return true; }
+    } else {
       const T act = e.f - en.f;
       if (t2_finite(en.f) && act >= T(0)) {
         const T rho = pred > T(0) ? act / pred : T(1);
@@ -186,22 +181,65 @@ T2_HD void lm_solve(const ObjCtx& c, const double* lbd, const double* ubd, LaneR
         nu = T(2);
         for (int j = 0; j < 3; ++j) q[j] = qn[j];
         e = en;
-        if (rel <= xtol || act <= (T)LmTol<T>::ftiny * e.f) { status = T2FIT_ST_CONVERGED; ++it; break; }
+#if !defined(__HIP_DEVICE_COMPILE__)
+        if (c.trace && *c.trace_n < c.trace_cap) {
+          double* tr = c.trace + 4 * (*c.trace_n)++;
+          tr[0] = NP == 3 ? sqrt((double)q[0]) : (double)q[0]; tr[1] = 1.0 / (double)q[1];
+          tr[2] = (double)lambda; tr[3] = (double)e.f / c.P->n_te;
+        }
+#endif
+        if (rel <= xtol || act <= (T)LmTol<T>::ftiny * e.f) { status = T2FIT_ST_CONVERGED; ++it; return true; }
       } else {
         lambda *= nu;
         nu *= T(2);
-        if (lambda > T(1e14)) { status = T2FIT_ST_CONVERGED; break; }  // no descent left at any damping
+        if (lambda > T(1e14)) { status = T2FIT_ST_CONVERGED; return true; }  // no descent left at any damping
       }
+      ++it;
+      if (it >= maxit) return true;
     }
+    // propose the next point: active set from the gradient sign at the bounds, damped step, clip
+    bool fixed[3];
+    for (int j = 0; j < 3; ++j)
+      fixed[j] = (q[j] <= lo[j] && e.g[j] < T(0)) || (q[j] >= hi[j] && e.g[j] > T(0));
+    lm_step<T, NP>(e, lambda, fixed, d);
+    bool moved = false;
+    rel = 0;
+    for (int j = 0; j < 3; ++j) {
+      qn[j] = t2_clip(q[j] + d[j], lo[j], hi[j]);
+      if (j >= NP) qn[j] = 0;
+      const T dj = qn[j] - q[j];
+      moved = moved || dj != T(0);
+      rel = t2_max(rel, t2_abs(dj) / (t2_abs(q[j]) + (j == 1 ? T(1e-6) : (NP == 3 ? T(1) : T(1e-3)))));
+    }
+    if (!moved) { status = T2FIT_ST_CONVERGED; return true; }
+    // predicted reduction of the (unclipped) damped model: d^T (lambda D d + g)
+    pred = 0;
+    const T dd[3] = {e.a[0], e.a[3], e.a[5]};
+    for (int j = 0; j < NP; ++j) pred += d[j] * (lambda * t2_max(dd[j], T(1e-30)) * d[j] + e.g[j]);
+    return false;
   }
-  out.x[0] = (double)q[0];
-  // snap T2 exactly onto a bound the rate sits on (1/(1/b) need not round-trip)
-  out.x[1] = q[1] <= lo[1] ? ubd[1] : (q[1] >= hi[1] ? lbd[1] : 1.0 / (double)q[1]);
-  out.x[2] = (NP == 3) ? (double)q[2] : 0.0;
-  out.fun = (double)e.f / n;
-  out.nit = it;
-  out.nfev = it + 1;
-  out.status = status;
+
+  T2_HD void result(const ObjCtx& c, LaneResult& out) const {
+    // back to (k, T2, sigma); a coordinate sitting on a bound is snapped onto it exactly
+    out.x[0] = NP == 3 ? (q[0] <= lo[0] && lbd[0] > 0.0 ? lbd[0] : (q[0] >= hi[0] ? ubd[0] : sqrt((double)q[0])))
+                       : (double)q[0];
+    out.x[1] = q[1] <= lo[1] ? ubd[1] : (q[1] >= hi[1] ? lbd[1] : 1.0 / (double)q[1]);
+    out.x[2] = (NP == 3) ? (q[2] <= lo[2] && lbd[2] > 0.0 ? lbd[2] : (q[2] >= hi[2] ? ubd[2] : sqrt((double)q[2]))) : 0.0;
+    out.fun = (double)e.f / c.P->n_te;
+    out.nit = it;
+    out.nfev = it + 1;
+    out.status = status;
+  }
+};
+
+template <typename T, int NP>
+T2_HD void lm_solve(const ObjCtx& c, const double* lbd, const double* ubd, LaneResult& out) {
+  LmLane<T, NP> s;
+  s.init(c, c.P->x0, lbd, ubd);
+  do {
+    s.eval(c);
+  } while (!s.advance(c));
+  s.result(c, out);
 }
 
 }  // namespace t2fit

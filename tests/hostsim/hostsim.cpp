@@ -58,7 +58,10 @@ extern "C" int hostsim_trace_row(const t2fit_config* cfg, const float* row, doub
   double lb[3], ub[3];
   if (!lane_bounds(P, y0_raw, lb, ub) || !finite) return -10;
   LaneResult r;
-  if (P.model == T2FIT_MODEL_GAUSSIAN) lbfgsb_solve<T2FIT_MODEL_GAUSSIAN>(c, lb, ub, r);
+  if (P.solver == T2FIT_SOLVER_LM) {
+    if (P.model == T2FIT_MODEL_GAUSSIAN) lm_solve<double, 2>(c, lb, ub, r);
+    else lm_solve<double, 3>(c, lb, ub, r);
+  } else if (P.model == T2FIT_MODEL_GAUSSIAN) lbfgsb_solve<T2FIT_MODEL_GAUSSIAN>(c, lb, ub, r);
   else if (P.model == T2FIT_MODEL_GAUSSIAN_RICIAN) lbfgsb_solve<T2FIT_MODEL_GAUSSIAN_RICIAN>(c, lb, ub, r);
   else lbfgsb_solve<T2FIT_MODEL_RICIAN>(c, lb, ub, r);
   for (int j = 0; j < 3; ++j) x[j] = r.x[j];
