@@ -134,26 +134,48 @@ def main():
     log(f"synthetic slab on device: {n_vox} voxels x {a.n_te} TE")
     table = t2.fit_table(a.fit, True)
     cfg = t2.make_config(a.fit, table, te, prior=not a.no_prior, norm=False, solver=a.solver, precision=a.precision)
-    # packed output slab [4, n_vox]: t2, k, sigma, res -- one all-gather moves all four maps
-    packed = torch.empty((4, n_vox), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world, 4, n_vox), dtype=torch.float32, device=dev) if world > 1 and not a.no_gather else None
-    maps = _abi.T2FitMaps()
-    maps.t2, maps.k, maps.sigma, maps.res = (packed[j].data_ptr() for j in range(4))
+    # packed output slab [4, n_vox]: t2, k, sigma, res -- one all-gather moves all four maps.
+    # Two slabs / two gather targets alternate so that the RCCL all-gather of step i (RCCL's own
+    # stream, xGMI) overlaps the fit kernel of step i+1; a slab is reused only after the gather that
+    # read it has been waited for on the compute stream.
+    do_gather = world > 1 and not a.no_gather
+    packed = [torch.empty((4, n_vox), dtype=torch.float32, device=dev) for _ in range(2 if do_gather else 1)]
+    gathered = [torch.empty((world, 4, n_vox), dtype=torch.float32, device=dev) for _ in range(2)] if do_gather else None
+    maps_b = []
+    for pk in packed:
+        mb = _abi.T2FitMaps()
+        mb.t2, mb.k, mb.sigma, mb.res = (pk[j].data_ptr() for j in range(4))
+        maps_b.append(mb)
+    maps = maps_b[0]
+    pending = [None, None]
     stream = torch.cuda.current_stream()
     st = C.c_void_p(stream.cuda_stream)
     lib.t2fit_set_timing(1)
     kernel_ms = []
+    step_no = [0]
 
     def step(record):
+        b = step_no[0] % len(packed)
+        step_no[0] += 1
+        if pending[b] is not None:
+            pending[b].wait()  # stream-side wait: slab b is free again
+            pending[b] = None
         check(lib.t2fit_volume_dev(C.byref(cfg), echoes.data_ptr(), _abi.LAYOUT_TE_MAJOR, mask.data_ptr(), n_vox,
-                                   C.byref(maps), st))
-        if gathered is not None:
-            dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1))
+                                   C.byref(maps_b[b]), st))
+        if do_gather:
+            pending[b] = dist.all_gather_into_tensor(gathered[b].view(-1), packed[b].view(-1), async_op=True)
         if record:
             kernel_ms.append(lib.t2fit_last_kernel_ms())  # syncs on the kernel's stop event only
 
+    def drain():
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+
     for _ in range(a.warmup):
         step(False)
+        drain()
         torch.cuda.synchronize()
         log("warmup step done")
     if world > 1:
@@ -162,6 +184,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step(True)
+    drain()  # every all-gather of the timed steps has completed inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -222,7 +245,7 @@ def main():
                                    f"{'prior' if not a.no_prior else 'no-prior'} bounds, mask fill {masked / n_vox:.2f}",
                        "solver": a.solver, "fit": a.fit, "n_te": a.n_te, "voxels_per_gpu": n_vox,
                        "masked_voxels_per_gpu": masked,
-                       "parallelism": f"voxel slabs x{world}" + (" + all-gather of 4 maps" if gathered is not None else "")},
+                       "parallelism": f"voxel slabs x{world}" + (" + all-gather of 4 maps (overlapped with the next fit)" if do_gather else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel": "fit_persistent_kernel", "kernel_ms": round(k_ms, 4),
