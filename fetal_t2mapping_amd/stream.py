@@ -1,0 +1,93 @@
+"""Streaming many subjects through one GPU (BASELINE.json config 5: 32 x 256^3 x 8 TE).
+
+The reference handles subjects one after another inside ``process_t2maps`` (run_t2mapping.py:358).
+Here the host->HBM copy of subject s+1 and the HBM->host copy of subject s-1 overlap the fit of
+subject s: pinned staging buffers, one copy stream per direction, HIP events for the hand-offs.
+Results are identical to calling ``fit_volume`` per subject (voxels are independent).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Iterator, Optional, Tuple
+
+import numpy as np
+
+from . import _abi
+from ._lib import check, require_gpu
+from .t2map import T2Maps, make_config
+
+
+class _Slot:
+    def __init__(self, dev):
+        self.dev = dev
+        self.cap_e = self.cap_n = 0
+        self.meta = None
+
+    def ensure(self, n_te: int, n: int):
+        import torch
+
+        if n_te * n > self.cap_e or n > self.cap_n:
+            self.cap_e, self.cap_n = max(self.cap_e, n_te * n), max(self.cap_n, n)
+            self.h_in = torch.empty(self.cap_e, dtype=torch.float32).pin_memory()
+            self.h_mask = torch.empty(self.cap_n, dtype=torch.uint8).pin_memory()
+            self.h_out = torch.empty(4 * self.cap_n, dtype=torch.float32).pin_memory()
+            self.d_in = torch.empty(self.cap_e, dtype=torch.float32, device=self.dev)
+            self.d_mask = torch.empty(self.cap_n, dtype=torch.uint8, device=self.dev)
+            self.d_out = torch.empty(4 * self.cap_n, dtype=torch.float32, device=self.dev)
+            self.ev_h2d, self.ev_fit, self.ev_d2h = (torch.cuda.Event() for _ in range(3))
+
+
+def fit_subjects(subjects: Iterable[Tuple[np.ndarray, Optional[np.ndarray]]], TEeffs, fit, fit_params, prior=True,
+                 norm=False, *, solver="lbfgsb", precision="f64", device=0, depth=2) -> Iterator[T2Maps]:
+    """Yield the maps of each ``(echoes (nTE,Z,Y,X) float32, mask (Z,Y,X) or None)`` in order."""
+    import torch
+
+    lib = require_gpu()
+    cfg = make_config(fit, fit_params, TEeffs, prior, norm, solver, precision)
+    dev = torch.device("cuda", device)
+    with torch.cuda.device(dev):
+        compute = torch.cuda.current_stream()
+        s_in, s_out = torch.cuda.Stream(), torch.cuda.Stream()
+        slots = [_Slot(dev) for _ in range(depth)]
+
+        def finish(slot):
+            slot.ev_d2h.synchronize()
+            shape, n = slot.meta
+            out = slot.h_out[: 4 * n].numpy().reshape(4, n).copy()
+            slot.meta = None
+            return T2Maps(*(out[j].reshape(shape) for j in range(4)))
+
+        n_sub = 0
+        for s, (echoes, mask) in enumerate(subjects):
+            n_sub = s + 1
+            slot = slots[s % depth]
+            if slot.meta is not None:
+                yield finish(slot)  # also frees the slot's pinned buffers for reuse
+            n_te = echoes.shape[0]
+            if n_te != cfg.n_te:
+                raise ValueError("every subject must have the configured number of echoes")
+            shape = tuple(echoes.shape[1:])
+            n = int(np.prod(shape))
+            slot.ensure(n_te, n)
+            slot.h_in[: n_te * n].numpy()[:] = np.asarray(echoes, np.float32).reshape(-1)
+            slot.h_mask[:n].numpy()[:] = 1 if mask is None else (np.asarray(mask).reshape(-1) != 0)
+            with torch.cuda.stream(s_in):
+                slot.d_in[: n_te * n].copy_(slot.h_in[: n_te * n], non_blocking=True)
+                slot.d_mask[:n].copy_(slot.h_mask[:n], non_blocking=True)
+                slot.ev_h2d.record(s_in)
+            compute.wait_event(slot.ev_h2d)
+            maps = _abi.T2FitMaps()
+            base = slot.d_out.data_ptr()
+            maps.t2, maps.k, maps.sigma, maps.res = (base + 4 * n * j for j in range(4))
+            check(lib.t2fit_volume_dev(C.byref(cfg), slot.d_in.data_ptr(), _abi.LAYOUT_TE_MAJOR, slot.d_mask.data_ptr(),
+                                       n, C.byref(maps), C.c_void_p(compute.cuda_stream)))
+            slot.ev_fit.record(compute)
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(slot.ev_fit)
+                slot.h_out[: 4 * n].copy_(slot.d_out[: 4 * n], non_blocking=True)
+                slot.ev_d2h.record(s_out)
+            slot.meta = (shape, n)
+        for k in range(n_sub - min(depth, n_sub), n_sub):  # drain in submission order
+            slot = slots[k % depth]
+            if slot.meta is not None:
+                yield finish(slot)
