@@ -117,3 +117,32 @@ def brain_volume_torch(shape, n_te: int, seed: int, device, sigma: float = 20.0,
         n2 = torch.randn(n_vox, generator=g, device=device) * sigma
         echoes[i] = torch.hypot(clean + n1, n2)
     return echoes, mask.to(torch.uint8), te
+
+
+def phantom_volume(shape=(20, 64, 64), n_te: int = 6, seed: int = SEED_BASE, low_field: bool = False,
+                   sigma: float = 15.0, k: float = 2000.0):
+    """NIST-phantom-like volume (BASELINE.json config 1: 64x64x20 x 6 TE): one cylinder per vial with
+    the NMR ground-truth T2 of the reference's table (run_t2mapping.py:19,24), Rician noise.
+    Returns ``(echoes (nTE,Z,Y,X) f32, mask (Z,Y,X) u8, label (Z,Y,X) i16, te, t2_truth list)``."""
+    gt = [594, 416, 284, 221, 167, 122, 80, 53, 41] if low_field else [1044, 624, 428, 258, 186, 137, 90, 63, 44, 27, 19,
+                                                                        15, 10, 8]
+    rng = np.random.default_rng(seed)
+    z, y, x = shape
+    te = te_vector(n_te, low_field)
+    label = np.zeros(shape, np.int16)
+    yy, xx = np.meshgrid(np.arange(y), np.arange(x), indexing="ij")
+    n = len(gt)
+    for i in range(n):
+        ang = 2 * np.pi * i / n
+        cy, cx = y / 2 + 0.36 * y * np.sin(ang), x / 2 + 0.36 * x * np.cos(ang)
+        disc = (yy - cy) ** 2 + (xx - cx) ** 2 <= (0.055 * min(y, x)) ** 2
+        label[z // 4: z - z // 4, disc] = i + 1
+    body = (yy - y / 2) ** 2 + (xx - x / 2) ** 2 <= (0.47 * min(y, x)) ** 2
+    mask = np.broadcast_to(body, shape).astype(np.uint8).copy()
+    t2 = np.full(shape, 2200.0)  # water-like fill between the vials
+    for i, v in enumerate(gt):
+        t2[label == i + 1] = v
+    clean = np.where(mask != 0, k, 0.0)[None] * np.exp(-te[:, None, None, None] / t2[None])
+    n1 = rng.normal(scale=sigma, size=clean.shape)
+    n2 = rng.normal(scale=sigma, size=clean.shape)
+    return np.hypot(clean + n1, n2).astype(np.float32), mask, label, te, gt

@@ -359,3 +359,54 @@ def test_options_against_live_oracle(t2):
     assert np.array_equal(nit, [r[2] for r in refc]) and np.array_equal(ok, [r[1] for r in refc])
     # three iterations in: same iterates up to the forward-difference noise (f ~ 1e-4 on normalised data)
     assert np.allclose(x, np.array([r[0] for r in refc]), rtol=5e-3, atol=1e-6)
+
+
+def test_phantom_config1_vial_means_match_oracle(t2):
+    """BASELINE.json config 1 (NIST phantom 64x64x20 x 6 TE, the reference's own CPU-runnable case):
+    fit the labelled vials on the GPU and with the oracle, compare per-vial mean T2 (what
+    save_phantom_csv reports, utils/t2map_utils.py:30-59) and the per-voxel maps."""
+    import multiprocessing as mp
+
+    from fetal_t2mapping_amd import synth
+    from oracle import t2fit_oracle as O
+
+    echoes, mask, label, te, gt = synth.phantom_volume()
+    roi = ((label > 0) & (mask != 0)).astype(np.uint8)  # --in_vitro_fast: only labelled voxels (:394-400)
+    table = t2.fit_table("gaussian", False)
+    maps = t2.fit_volume(echoes, roi, te, "gaussian", table, prior=False, extras=True)
+    data, _, idx = O.stack_mask_flatten(list(echoes), [roi] * len(te))
+    with mp.get_context("fork").Pool(8) as pool:
+        ref = O.fit_volume(data, idx, te, "gaussian", O.fit_table("gaussian", False), prior=False, pool=pool)
+    dt = np.abs(maps.t2.reshape(-1)[idx] - ref.t2[idx])
+    assert np.mean(dt <= T2_TOL_MS) >= 0.95 and np.median(dt) <= 0.02
+    for i, truth in enumerate(gt):
+        if truth < 60:  # signal gone before the first echo (115 ms): T2 is noise there, in both
+            continue
+        sel = label.reshape(-1) == i + 1
+        m_gpu, m_ref = float(np.nanmean(maps.t2.reshape(-1)[sel])), float(np.nanmean(ref.t2[sel]))
+        assert abs(m_gpu - m_ref) <= max(1.0, 0.01 * m_ref), (i, m_gpu, m_ref)
+    assert np.all(maps.t2[roi == 0] == 0)
+
+
+@pytest.mark.parametrize("n_te", [2, 9, 16, 17, 32])
+def test_echo_train_lengths(t2, n_te):
+    """Shortest / longest echo trains and the ones around the 8- and 16-echo code paths: the lane
+    solver against the live oracle (reference-trajectory) and the LM solver against it where the
+    2-parameter reference converges."""
+    from fetal_t2mapping_amd import synth
+    from oracle import t2fit_oracle as O
+
+    rng = np.random.default_rng(n_te)
+    te = np.linspace(20.0, 20.0 + 25.0 * n_te, n_te)
+    y, _ = synth.voxels(rng, te, 96, t2_range=(40.0, 500.0), sigmas=(5.0, 20.0))
+    table = t2.fit_table("gaussian", True)
+    x, ok, nit, fun, st = t2.fit_voxels(np.arange(len(y)), "gaussian", table, te, y, True, False)
+    ref = np.array([O.fit_voxel(v, "gaussian", t2.fit_table("gaussian", True), te, y, True, False, want_trace=False)[0]
+                    for v in range(len(y))])
+    dt = np.abs(x[:, 1] - ref[:, 1])
+    assert np.mean(dt <= T2_TOL_MS) >= 0.93 and np.median(dt) <= 0.05, (np.mean(dt <= 1), np.median(dt))
+    xl, okl, _, _, _ = t2.fit_voxels(np.arange(len(y)), "gaussian", table, te, y, True, False, solver="lm")
+    assert np.mean(np.abs(xl[:, 1] - ref[:, 1]) <= T2_TOL_MS) >= 0.9
+    x3, _, _, _, st3 = t2.fit_voxels(np.arange(len(y)), "gaussian_rician", t2.fit_table("gaussian_rician", True), te, y,
+                                     True, False)
+    assert np.all(st3 != 0) and np.all(np.isfinite(x3))
