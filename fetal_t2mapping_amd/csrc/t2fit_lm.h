@@ -80,18 +80,21 @@ T2_HD void lm_step(const LmEval<T>& e, T lambda, const bool* fixed, T* d) {
   if (fixed[0]) { a00 = 1; a01 = 0; a02 = 0; g0 = 0; }
   if (fixed[1]) { a11 = 1; a01 = 0; a12 = 0; g1 = 0; }
   if (NP == 2 || fixed[2]) { a22 = 1; a02 = 0; a12 = 0; g2 = 0; }
-  // LDL^T of the symmetric 3x3
-  const T d0 = a00;
-  const T l10 = a01 / d0, l20 = a02 / d0;
+  // LDL^T of the symmetric 3x3; three reciprocals instead of six divisions (the step is only a
+  // proposal: it is accepted or rejected on the objective, so its last bits do not matter)
+  const T r0 = t2_rcp(a00);
+  const T l10 = a01 * r0, l20 = a02 * r0;
   const T d1 = a11 - l10 * a01;
-  const T l21 = (a12 - l20 * a01) / d1;
+  const T r1 = t2_rcp(d1);
+  const T l21 = (a12 - l20 * a01) * r1;
   const T d2 = a22 - l20 * a02 - l21 * (a12 - l20 * a01);
+  const T r2 = t2_rcp(d2);
   const T z0 = g0;
   const T z1 = g1 - l10 * z0;
   const T z2 = g2 - l20 * z0 - l21 * z1;
-  const T x2 = z2 / d2;
-  const T x1 = z1 / d1 - l21 * x2;
-  const T x0 = z0 / d0 - l10 * x1 - l20 * x2;
+  const T x2 = z2 * r2;
+  const T x1 = z1 * r1 - l21 * x2;
+  const T x0 = z0 * r0 - l10 * x1 - l20 * x2;
   d[0] = x0; d[1] = x1; d[2] = x2;
 }
 
@@ -136,6 +139,12 @@ struct LmLane {
   int it, maxit;
   uint8_t status;
   bool first;
+  // second start: when the seeded run ends with T2 on a bound (decayed / flat / noise-only voxels,
+  // where the objective has one minimum at each end of the T2 interval) the fit is repeated from the
+  // table start point and the lower objective wins
+  int stage;
+  T qbest[3], fbest, x0q[3];
+  uint8_t sbest;
 
   T2_HD void init(const ObjCtx& c, const double* x0, const double* lb_, const double* ub_) {
     const LaneParams& P = *c.P;
@@ -148,10 +157,22 @@ struct LmLane {
     qn[0] = t2_clip(NP == 3 ? (T)sq(x0[0]) : (T)x0[0], lo[0], hi[0]);
     qn[1] = t2_clip((T)(1.0 / x0[1]), lo[1], hi[1]);
     qn[2] = (NP == 3) ? t2_clip((T)sq(x0[2]), lo[2], hi[2]) : T(0);
+    for (int j = 0; j < 3; ++j) x0q[j] = qn[j];
+    stage = 0;
     T ks, Rs;
     if (loglinear_seed<T>(c, ks, Rs)) {
       qn[0] = t2_clip(NP == 3 ? ks * ks : ks, lo[0], hi[0]);
       qn[1] = t2_clip(Rs, lo[1], hi[1]);
+      if (NP == 3) {
+        // noise-floor seed: m^2 = a E^2 + u, so u ~ mean(y^2 - a E^2) at the seeded (a, R)
+        T acc = 0;
+        for (int i = 0; i < P.n_te; ++i) {
+          const T y = (T)c.sample(i);
+          acc += y * y - qn[0] * t2_exp(T(-2) * TeOf<T>::at(P, i) * qn[1]);
+        }
+        const T u = acc / (T)P.n_te;
+        if (t2_finite(u)) qn[2] = t2_clip(u, lo[2], hi[2]);
+      }
     }
     xtol = P.lm_xtol > 0 ? (T)P.lm_xtol : (T)LmTol<T>::xtol;
     lambda = T(1e-3);
@@ -164,7 +185,38 @@ struct LmLane {
 
   T2_HD void eval(const ObjCtx& c) { lm_eval<T, NP>(c, qn, en); }
 
+  // the current run has ended with `status`; returns false if a second run was started instead
+  T2_HD bool finish_run() {
+    const bool at_t2_bound = q[1] <= lo[1] || q[1] >= hi[1];
+    if (stage == 0 && at_t2_bound && status != T2FIT_ST_NONFINITE && it < maxit) {
+      bool same = true;
+      for (int j = 0; j < 3; ++j) same = same && x0q[j] == q[j];
+      if (!same) {
+        stage = 1;
+        for (int j = 0; j < 3; ++j) { qbest[j] = q[j]; qn[j] = x0q[j]; }
+        fbest = e.f;
+        sbest = status;
+        lambda = T(1e-3);
+        nu = T(2);
+        status = T2FIT_ST_NOT_CONV;
+        first = true;
+        return false;
+      }
+    }
+    if (stage == 1 && !(e.f < fbest)) {  // the seeded run was at least as good: keep it
+      for (int j = 0; j < 3; ++j) q[j] = qbest[j];
+      e.f = fbest;
+      status = sbest;
+    }
+    return true;
+  }
+
   T2_HD bool advance(const ObjCtx& c) {
+    if (!step(c)) return false;
+    return finish_run();
+  }
+
+  T2_HD bool step(const ObjCtx& c) {
     if (first) {
       first = false;
       for (int j = 0; j < 3; ++j) q[j] = qn[j];
@@ -173,7 +225,7 @@ struct LmLane {
     } else {
       const T act = e.f - en.f;
       if (t2_finite(en.f) && act >= T(0)) {
-        const T rho = pred > T(0) ? act / pred : T(1);
+        const T rho = pred > T(0) ? act * t2_rcp(pred) : T(1);
         T fac = T(2) * rho - T(1);
         fac = T(1) - fac * fac * fac;
         lambda *= t2_max(T(1) / T(3), fac);
@@ -209,7 +261,7 @@ struct LmLane {
       if (j >= NP) qn[j] = 0;
       const T dj = qn[j] - q[j];
       moved = moved || dj != T(0);
-      rel = t2_max(rel, t2_abs(dj) / (t2_abs(q[j]) + (j == 1 ? T(1e-6) : (NP == 3 ? T(1) : T(1e-3)))));
+      rel = t2_max(rel, t2_abs(dj) * t2_rcp(t2_abs(q[j]) + (j == 1 ? T(1e-6) : (NP == 3 ? T(1) : T(1e-3)))));
     }
     if (!moved) { status = T2FIT_ST_CONVERGED; return true; }
     // predicted reduction of the (unclipped) damped model: d^T (lambda D d + g)
