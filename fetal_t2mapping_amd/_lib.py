@@ -8,7 +8,8 @@ import os
 from . import _abi
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libt2fit_hip.so")
+# T2FIT_LIB selects another build of the same library (diagnostic builds under tools/diag/)
+LIB_PATH = os.environ.get("T2FIT_LIB") or os.path.join(_PKG, "lib", "libt2fit_hip.so")
 
 _lib = None
 

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <string>
@@ -195,6 +196,12 @@ __global__ __launch_bounds__(kBlock) void fit_persistent_kernel(const LaneParams
   double box_x0[3], box_lb[3], box_ub[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) { box_x0[j] = P.x0[j]; box_lb[j] = P.lb[j]; box_ub[j] = P.ub[j]; }
+#if defined(T2_PHASE_STAMPS)  // diagnostic build only: where do a wave's cycles go?
+  unsigned long long st_refill = 0, st_eval = 0, st_adv = 0, st_t = __builtin_amdgcn_s_memtime();
+#define T2_STAMP(acc) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc += n_ - st_t; st_t = n_; }
+#else
+#define T2_STAMP(acc)
+#endif
   for (;;) {
     // Refill in batches: the refill path (sample loads, seed / set-up) runs with only the idle lanes
     // active, so it is entered when at least refill_min lanes are idle (or nothing is running).
@@ -298,12 +305,14 @@ __global__ __launch_bounds__(kBlock) void fit_persistent_kernel(const LaneParams
         }
       }
     }
+    T2_STAMP(st_refill)
     if (__ballot(busy) == 0ull) {
       if (!chunks_left && q_count == 0) break;
       continue;
     }
+    if (busy) s.eval(c);
+    T2_STAMP(st_eval)
     if (busy) {
-      s.eval(c);
       if (s.advance(c)) {
         LaneResult r;
         A::result(s, c, r);
@@ -311,7 +320,17 @@ __global__ __launch_bounds__(kBlock) void fit_persistent_kernel(const LaneParams
         busy = false;
       }
     }
+    T2_STAMP(st_adv)
   }
+#if defined(T2_PHASE_STAMPS)
+  if (lane == 0) {
+    atomicAdd(next_chunk + 1, st_refill);
+    atomicAdd(next_chunk + 2, st_eval);
+    atomicAdd(next_chunk + 3, st_adv);
+    if constexpr (A::kHistDoubles > 0)
+      for (int j = 0; j < 6; ++j) atomicAdd(next_chunk + 4 + j, s.stamp[j]);
+  }
+#endif
 }
 
 // Residual map (utils/t2map_utils.py:62-89) and optional R^2 from float32 maps already on the device.
@@ -494,8 +513,8 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
   if (persistent && n_vox >= 0xffffffffLL) return fail(T2FIT_E_INVALID, "n_vox must be below 2^32 per call");
   unsigned long long* counter = nullptr;
   if (persistent) {
-    T2_HIP(hipMallocAsync((void**)&counter, sizeof(unsigned long long), st));
-    T2_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
+    T2_HIP(hipMallocAsync((void**)&counter, 16 * sizeof(unsigned long long), st));
+    T2_HIP(hipMemsetAsync(counter, 0, 16 * sizeof(unsigned long long), st));
   }
   if (g_timing) {
     if (!g_ev0) {
@@ -537,6 +556,19 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
     T2_HIP(hipEventRecord(g_ev1, st));
     g_ev_valid = true;
   }
+#if defined(T2_PHASE_STAMPS)
+  if (counter) {
+    unsigned long long h[16];
+    T2_HIP(hipMemcpyAsync(h, counter, sizeof(h), hipMemcpyDeviceToHost, st));
+    T2_HIP(hipStreamSynchronize(st));
+    const double tot = (double)(h[1] + h[2] + h[3]);
+    fprintf(stderr, "[t2fit stamps] refill %.1f%%  eval %.1f%%  advance %.1f%%  (wave-cycles %.3g)\n",
+            100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, tot);
+    if (h[4] + h[5] + h[6])
+      fprintf(stderr, "[t2fit stamps] advance: digest %.1f%%  build_b %.1f%%  cauchy %.1f%%  subsm %.1f%%  ls-setup %.1f%%  loop-glue %.1f%%  (of all wave-cycles)\n",
+              100.0 * h[4] / tot, 100.0 * h[5] / tot, 100.0 * h[6] / tot, 100.0 * h[7] / tot, 100.0 * h[8] / tot, 100.0 * h[9] / tot);
+  }
+#endif
   if (counter) T2_HIP(hipFreeAsync(counter, st));
   return T2FIT_OK;
 }

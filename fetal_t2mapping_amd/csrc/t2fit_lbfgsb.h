@@ -109,82 +109,68 @@ struct LsState {
 
 T2_HD double t2_max3(double a, double b, double c) { return t2_max(a, t2_max(b, c)); }
 
+// One safeguarded cubic / secant step (MINPACK-2 dcstep).  The four cases of the original share
+// their cubic-interpolation arithmetic, so it is computed once on operands selected by case: the
+// lanes of a wave usually sit in different cases, and four inlined copies of the divisions and the
+// square root would otherwise run one after the other.  Every value is formed by the same
+// operations, in the same order, as in the case-by-case form (3*(fp-fy)/(sty-stp) and
+// 3*(fy-fp)/(stp-sty) are the same floating-point number).
 T2_HD void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy, double& dy, double& stp,
                   double fp, double dp, bool& brackt, double stpmin, double stpmax) {
   const double sgnd = dp * (dx / t2_abs(dx));
+  const bool c1 = fp > fx;                              // higher function value: minimum bracketed
+  const bool c2 = !c1 && sgnd < 0.0;                    // derivatives of opposite sign: bracketed
+  const bool c3 = !c1 && !c2 && t2_abs(dp) < t2_abs(dx);  // derivative magnitude decreases
+  const bool c4 = !c1 && !c2 && !c3;                    // derivative does not decrease
+  // cubic through (sta, fa, da) and (stp, fp, dp): a = y in case 4, a = x otherwise
+  const double sta = c4 ? sty : stx, fa = c4 ? fy : fx, da = c4 ? dy : dx;
+  const double theta = 3.0 * (fa - fp) / (stp - sta) + da + dp;
+  const double s = t2_max3(t2_abs(theta), t2_abs(da), t2_abs(dp));
+  const double ts = theta / s;
+  double arg = ts * ts - (da / s) * (dp / s);
+  if (c3) arg = t2_max(0.0, arg);
+  double gamma = s * t2_sqrt(arg);
+  const bool flip = c1 ? stp < stx : (c4 ? stp > sty : stp > stx);
+  if (flip) gamma = -gamma;
+  const double gd1 = c1 ? dx : dp;  // the slope subtracted from gamma
+  const double p = (gamma - gd1) + theta;
+  const double q = c3 ? (gamma + (dx - dp)) + gamma : ((gamma - gd1) + gamma) + (c1 ? dp : (c2 ? dx : dy));
+  const double r = p / q;
+  // cubic step
+  double stpc = c1 ? stx + r * (stp - stx) : stp + r * (sta - stp);
+  if (c3 && !(r < 0.0 && gamma != 0.0)) stpc = stp > stx ? stpmax : stpmin;
+  // quadratic (case 1) or secant (cases 2, 3) step
+  const double quad = c1 ? dx / ((fx - fp) / (stp - stx) + dx) / 2.0 : dp / (dp - dx);
+  const double stpq = c1 ? stx + quad * (stp - stx) : stp + quad * (stx - stp);
   double stpf;
-  if (fp > fx) {  // case 1: higher function value -> minimum bracketed
-    const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
-    const double s = t2_max3(t2_abs(theta), t2_abs(dx), t2_abs(dp));
-    double gamma = s * t2_sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
-    if (stp < stx) gamma = -gamma;
-    const double p = (gamma - dx) + theta;
-    const double q = ((gamma - dx) + gamma) + dp;
-    const double r = p / q;
-    const double stpc = stx + r * (stp - stx);
-    const double stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.0) * (stp - stx);
-    if (t2_abs(stpc - stx) < t2_abs(stpq - stx)) stpf = stpc;
-    else stpf = stpc + (stpq - stpc) / 2.0;
-    brackt = true;
-  } else if (sgnd < 0.0) {  // case 2: derivatives of opposite sign
-    const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
-    const double s = t2_max3(t2_abs(theta), t2_abs(dx), t2_abs(dp));
-    double gamma = s * t2_sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
-    if (stp > stx) gamma = -gamma;
-    const double p = (gamma - dp) + theta;
-    const double q = ((gamma - dp) + gamma) + dx;
-    const double r = p / q;
-    const double stpc = stp + r * (stx - stp);
-    const double stpq = stp + (dp / (dp - dx)) * (stx - stp);
-    if (t2_abs(stpc - stp) > t2_abs(stpq - stp)) stpf = stpc;
-    else stpf = stpq;
-    brackt = true;
-  } else if (t2_abs(dp) < t2_abs(dx)) {  // case 3: derivative magnitude decreases
-    const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
-    const double s = t2_max3(t2_abs(theta), t2_abs(dx), t2_abs(dp));
-    double gamma = s * t2_sqrt(t2_max(0.0, (theta / s) * (theta / s) - (dx / s) * (dp / s)));
-    if (stp > stx) gamma = -gamma;
-    const double p = (gamma - dp) + theta;
-    const double q = (gamma + (dx - dp)) + gamma;
-    const double r = p / q;
-    double stpc;
-    if (r < 0.0 && gamma != 0.0) stpc = stp + r * (stx - stp);
-    else if (stp > stx) stpc = stpmax;
-    else stpc = stpmin;
-    const double stpq = stp + (dp / (dp - dx)) * (stx - stp);
+  if (c1) {
+    stpf = t2_abs(stpc - stx) < t2_abs(stpq - stx) ? stpc : stpc + (stpq - stpc) / 2.0;
+  } else if (c2) {
+    stpf = t2_abs(stpc - stp) > t2_abs(stpq - stp) ? stpc : stpq;
+  } else if (c3) {
     if (brackt) {
-      if (t2_abs(stpc - stp) < t2_abs(stpq - stp)) stpf = stpc;
-      else stpf = stpq;
-      if (stp > stx) stpf = t2_min(stp + 0.66 * (sty - stp), stpf);
-      else stpf = t2_max(stp + 0.66 * (sty - stp), stpf);
+      stpf = t2_abs(stpc - stp) < t2_abs(stpq - stp) ? stpc : stpq;
+      stpf = stp > stx ? t2_min(stp + 0.66 * (sty - stp), stpf) : t2_max(stp + 0.66 * (sty - stp), stpf);
     } else {
-      if (t2_abs(stpc - stp) > t2_abs(stpq - stp)) stpf = stpc;
-      else stpf = stpq;
+      stpf = t2_abs(stpc - stp) > t2_abs(stpq - stp) ? stpc : stpq;
       stpf = t2_min(stpmax, stpf);
       stpf = t2_max(stpmin, stpf);
     }
-  } else {  // case 4: derivative does not decrease
-    if (brackt) {
-      const double theta = 3.0 * (fp - fy) / (sty - stp) + dy + dp;
-      const double s = t2_max3(t2_abs(theta), t2_abs(dy), t2_abs(dp));
-      double gamma = s * t2_sqrt((theta / s) * (theta / s) - (dy / s) * (dp / s));
-      if (stp > sty) gamma = -gamma;
-      const double p = (gamma - dp) + theta;
-      const double q = ((gamma - dp) + gamma) + dy;
-      const double r = p / q;
-      stpf = stp + r * (sty - stp);
-    } else if (stp > stx) {
-      stpf = stpmax;
-    } else {
-      stpf = stpmin;
-    }
-  }
-  if (fp > fx) {
-    sty = stp; fy = fp; dy = dp;
   } else {
-    if (sgnd < 0.0) { sty = stx; fy = fx; dy = dx; }
-    stx = stp; fx = fp; dx = dp;
+    stpf = brackt ? stpc : (stp > stx ? stpmax : stpmin);
   }
+  if (c1 || c2) brackt = true;
+  // interval update, written as value selects (conditional stores through the reference
+  // parameters made the compiler keep the six values in scratch memory)
+  const bool swap = !c1 && sgnd < 0.0;
+  const double nsty = c1 ? stp : (swap ? stx : sty);
+  const double nfy = c1 ? fp : (swap ? fx : fy);
+  const double ndy = c1 ? dp : (swap ? dx : dy);
+  const double nstx = c1 ? stx : stp;
+  const double nfx = c1 ? fx : fp;
+  const double ndx = c1 ? dx : dp;
+  sty = nsty; fy = nfy; dy = ndy;
+  stx = nstx; fx = nfx; dx = ndx;
   stp = stpf;
 }
 
@@ -307,6 +293,16 @@ struct Lbfgsb {
   int col, nit, nfev, ifun;
   uint8_t status;
   bool first;
+#if defined(T2_PHASE_STAMPS)
+  unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0}, stamp_t = 0;  // diagnostic build: cycles per advance() block
+#endif
+#if defined(T2_PHASE_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define T2_LSTAMP0() stamp_t = __builtin_amdgcn_s_memtime();
+#define T2_LSTAMP(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); stamp[i] += n_ - stamp_t; stamp_t = n_; }
+#else
+#define T2_LSTAMP0()
+#define T2_LSTAMP(i)
+#endif
 
   // scipy ScalarFunction.fun_and_grad with approx_derivative('2-point', abs_step=h, bounds): all N+1
   // objective values in one pass over the echoes.  Evaluations that share T2 share their exp()
@@ -519,11 +515,22 @@ struct Lbfgsb {
     int nleft = nbreak;
     bool all_fixed = false;
     while (nleft > 0) {
-      int ibp = -1;
+      // next breakpoint: one-hot flags rather than an index, so that no local array is ever
+      // indexed by a run-time value (the compiler would move it to scratch memory)
+      bool pick[N];
+      bool any = false;
       double tmin = 0.0;
       T2_UNROLL
-      for (int i = 0; i < N; ++i)
-        if (hasbk[i] && (ibp < 0 || tbk[i] < tmin)) { ibp = i; tmin = tbk[i]; }
+      for (int i = 0; i < N; ++i) {
+        pick[i] = hasbk[i] && (!any || tbk[i] < tmin);
+        if (pick[i]) {
+          T2_UNROLL
+          for (int j = 0; j < N; ++j)
+            if (j < i) pick[j] = false;
+          any = true;
+          tmin = tbk[i];
+        }
+      }
       const double tj0 = tj;
       tj = tmin;
       const double dt = tj - tj0;
@@ -533,7 +540,7 @@ struct Lbfgsb {
       double dibp = 0.0;
       T2_UNROLL
       for (int i = 0; i < N; ++i)
-        if (i == ibp) {
+        if (pick[i]) {
           dibp = d[i];
           d[i] = 0.0;
           hasbk[i] = false;
@@ -621,7 +628,9 @@ struct Lbfgsb {
       T2_UNROLL
       for (int i = 0; i < N; ++i) z[i] = xp[i];
       double alpha = 1.0, temp1 = 1.0;
-      int ibd = -1;
+      bool hit[N];
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) hit[i] = false;
       T2_UNROLL
       for (int i = 0; i < N; ++i) {
         if (fr[i]) {
@@ -635,13 +644,17 @@ struct Lbfgsb {
             if (temp2 <= 0.0) temp1 = 0.0;
             else if (dk * alpha > temp2) temp1 = temp2 / dk;
           }
-          if (temp1 < alpha) { alpha = temp1; ibd = i; }
+          if (temp1 < alpha) {
+            alpha = temp1;
+            T2_UNROLL
+            for (int j = 0; j < N; ++j) hit[j] = j == i;
+          }
         }
       }
       if (alpha < 1.0) {
         T2_UNROLL
         for (int i = 0; i < N; ++i)
-          if (i == ibd) {
+          if (hit[i]) {
             if (du[i] > 0.0) { z[i] = ub[i]; du[i] = 0.0; }
             else if (du[i] < 0.0) { z[i] = lb[i]; du[i] = 0.0; }
           }
@@ -682,6 +695,7 @@ struct Lbfgsb {
     const double epsmch = 2.220446049250313e-16;
     enum { GO_BEGIN, GO_TRIAL, GO_FAIL, GO_DONE };
     int next;
+    T2_LSTAMP0()
     // ---- 1. digest the evaluation that just finished ----
     if (first) {
       first = false;
@@ -739,6 +753,7 @@ struct Lbfgsb {
         }
       }
     }
+    T2_LSTAMP(0)
     // ---- 2. (re)start iterations until one yields a trial point or the fit ends ----
     for (;;) {
       if (next == GO_FAIL) {
@@ -752,8 +767,11 @@ struct Lbfgsb {
       }
       if (next != GO_BEGIN) break;
       double B[N][N];
+      T2_LSTAMP(5)
       build_b(B);
+      T2_LSTAMP(1)
       cauchy(x, g, B, theta, sbgnrm, iwhere, z);
+      T2_LSTAMP(2)
       int nfree = 0;
       T2_UNROLL
       for (int i = 0; i < N; ++i) nfree += iwhere[i] <= 0;
@@ -763,6 +781,7 @@ struct Lbfgsb {
           continue;
         }
       }
+      T2_LSTAMP(3)
       // line search along d = z - x (lnsrlb)
       T2_UNROLL
       for (int i = 0; i < N; ++i) { d[i] = z[i] - x[i]; t[i] = x[i]; r[i] = g[i]; }
@@ -793,7 +812,9 @@ struct Lbfgsb {
       dcsrch_start(f, gd, stp, 1e-3, 0.0, stpmx, ls);  // ERROR also covers gd >= 0: not a descent direction
       ifun = 1;
       next = (ls.task != LS_FG || ifun - 1 >= P.maxls) ? GO_FAIL : GO_TRIAL;
+      T2_LSTAMP(4)
     }
+    T2_LSTAMP(5)
     if (next == GO_TRIAL) {
       T2_UNROLL
       for (int i = 0; i < N; ++i) x[i] = stp == 1.0 ? z[i] : stp * d[i] + t[i];
