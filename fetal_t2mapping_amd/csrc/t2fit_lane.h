@@ -64,6 +64,18 @@ T2_HD float t2_exp(float x) { return expf(x); }
 T2_HD float t2_rsqrt(float x) { return 1.0f / sqrtf(x); }
 T2_HD float t2_rcp(float x) { return 1.0f / x; }
 #endif
+// reciprocal good to ~1 ulp without the IEEE division sequence (v_rcp_f64 seed, two Newton steps);
+// used only where the last bit is immaterial (scalings inside the quasi-Newton matrix rebuild)
+#if defined(__HIP_DEVICE_COMPILE__)
+T2_HD double t2_fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+#else
+T2_HD double t2_fast_rcp(double x) { return 1.0 / x; }
+#endif
 T2_HD double t2_rsqrt(double x) { return 1.0 / sqrt(x); }
 T2_HD double t2_rcp(double x) { return 1.0 / x; }
 T2_HD float t2_sqrt(float x) { return sqrtf(x); }

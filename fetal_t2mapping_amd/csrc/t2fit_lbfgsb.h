@@ -452,7 +452,7 @@ struct Lbfgsb {
       }
       T2_UNROLL
       for (int i = 0; i < N; ++i) { sbs += sp[i] * bs[i]; ys += yp[i] * sp[i]; }
-      const double rys = 1.0 / ys, rsbs = 1.0 / sbs;
+      const double rys = t2_fast_rcp(ys), rsbs = t2_fast_rcp(sbs);
       double ty[N], tb[N];
       T2_UNROLL
       for (int i = 0; i < N; ++i) { ty[i] = yp[i] * rys; tb[i] = bs[i] * rsbs; }
