@@ -122,11 +122,19 @@ def main():
         cpu = cpu_baseline(rows, te_c, a.fit, not a.no_prior, a.cpu_seconds)
     log("cpu baseline done" if cpu else "no cpu baseline")
     lib = require_gpu()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # T2FIT_BENCH_BACKEND=gloo is a REHEARSAL of the N > 1 control flow on a one-GPU box: every rank
+    # uses cuda:0 and the gather is staged through the host.  Numbers from it mean nothing.
+    backend = os.environ.get("T2FIT_BENCH_BACKEND", "nccl")
+    rehearsal = backend != "nccl"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     z, y, x = a.shape
     n_vox = z * y * x
@@ -163,7 +171,12 @@ def main():
         check(lib.t2fit_volume_dev(C.byref(cfg), echoes.data_ptr(), _abi.LAYOUT_TE_MAJOR, mask.data_ptr(), n_vox,
                                    C.byref(maps_b[b]), st))
         if do_gather:
-            pending[b] = dist.all_gather_into_tensor(gathered[b].view(-1), packed[b].view(-1), async_op=True)
+            if rehearsal:
+                parts = [torch.empty((4, n_vox), dtype=torch.float32) for _ in range(world)]
+                dist.all_gather(parts, packed[b].cpu())
+                gathered[b].copy_(torch.stack(parts))
+            else:
+                pending[b] = dist.all_gather_into_tensor(gathered[b].view(-1), packed[b].view(-1), async_op=True)
         if record:
             kernel_ms.append(lib.t2fit_last_kernel_ms())  # syncs on the kernel's stop event only
 
@@ -191,7 +204,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -57,9 +57,11 @@ T2_HD double t2_sqrt(double x) { return sqrt(x); }
 T2_HD double t2_log(double x) { return log(x); }
 #if defined(__HIP_DEVICE_COMPILE__)
 T2_HD float t2_exp(float x) { return __expf(x); }        // v_exp_f32 path
+T2_HD float t2_log(float x) { return __logf(x); }        // v_log_f32 path (LM seed only)
 T2_HD float t2_rsqrt(float x) { return __frsqrt_rn(x); }  // v_rsq_f32
 T2_HD float t2_rcp(float x) { return __frcp_rn(x); }
 #else
+T2_HD float t2_log(float x) { return logf(x); }
 T2_HD float t2_exp(float x) { return expf(x); }
 T2_HD float t2_rsqrt(float x) { return 1.0f / sqrtf(x); }
 T2_HD float t2_rcp(float x) { return 1.0f / x; }
@@ -79,7 +81,6 @@ T2_HD double t2_fast_rcp(double x) { return 1.0 / x; }
 T2_HD double t2_rsqrt(double x) { return 1.0 / sqrt(x); }
 T2_HD double t2_rcp(double x) { return 1.0 / x; }
 T2_HD float t2_sqrt(float x) { return sqrtf(x); }
-T2_HD float t2_log(float x) { return logf(x); }
 
 template <typename T> T2_HD T t2_min(T a, T b) { return a < b ? a : b; }
 template <typename T> T2_HD T t2_max(T a, T b) { return a > b ? a : b; }
