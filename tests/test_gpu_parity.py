@@ -410,3 +410,45 @@ def test_echo_train_lengths(t2, n_te):
     x3, _, _, _, st3 = t2.fit_voxels(np.arange(len(y)), "gaussian_rician", t2.fit_table("gaussian_rician", True), te, y,
                                      True, False)
     assert np.all(st3 != 0) and np.all(np.isfinite(x3))
+
+
+def test_full_size_properties_256cubed(t2):
+    """BASELINE.json's headline size (256^3 x 8 TE, 3-parameter objective) through size-independent
+    properties: voxels are independent, so fitting the volume with its voxel order reversed must give
+    the reversed maps bit-for-bit (different chunks, queues and lanes handle each voxel); masked-out
+    voxels are exactly zero; every fitted voxel ends inside the box with a definite status; the
+    voxel-major layout gives the same bits as the TE-major one."""
+    import torch
+
+    from fetal_t2mapping_amd import _abi, synth
+
+    shape = (256, 256, 256)
+    n = shape[0] * shape[1] * shape[2]
+    echoes, mask, te = synth.brain_volume_torch(shape, 8, synth.SEED_BASE + 3, torch.device("cuda", 0))
+    table = t2.fit_table("gaussian_rician", True)
+    a = t2.fit_volume(echoes.reshape((8,) + shape), mask, te, "gaussian_rician", table, extras=True)
+    rev_e = torch.flip(echoes, dims=[1]).contiguous()
+    rev_m = torch.flip(mask, dims=[0]).contiguous()
+    b = t2.fit_volume(rev_e.reshape((8,) + shape), rev_m, te, "gaussian_rician", table, extras=True)
+    torch.cuda.synchronize()
+    for name in ("t2", "k", "sigma", "res", "nit", "status"):
+        x, y = getattr(a, name).reshape(-1), torch.flip(getattr(b, name).reshape(-1), dims=[0])
+        assert torch.equal(x, y) or bool(((x == y) | (x.isnan() & y.isnan())).all()), name
+    m = mask.bool()
+    assert int(m.sum()) == 7463192  # the synthetic mask is deterministic
+    for name in ("t2", "k", "sigma", "res"):
+        assert bool((getattr(a, name).reshape(-1)[~m] == 0).all())
+    st = a.status.reshape(-1)
+    assert bool((st[~m] == _abi.ST_MASKED).all()) and bool(((st[m] == 1) | (st[m] == 2)).all())
+    t2v, kv, sv = a.t2.reshape(-1)[m], a.k.reshape(-1)[m], a.sigma.reshape(-1)[m]
+    assert bool(((t2v >= 10) & (t2v <= 600) & (kv >= 550) & (kv <= 10000) & (sv >= 2) & (sv <= 1000)).all())
+    assert float((st[m] == 1).float().mean()) > 0.999  # scipy success
+    # plausibility against the generating distribution (T2 40..400 ms in the brain, 600..2000 in the CSF pocket)
+    assert 100.0 < float(t2v.median()) < 300.0
+    del b, rev_e, rev_m
+    vm = echoes.t().contiguous()  # (N, nTE)
+    c = t2.fit_volume(vm.reshape(shape + (8,)), mask, te, "gaussian_rician", table, layout="voxel_major")
+    torch.cuda.synchronize()
+    for name in ("t2", "k", "sigma", "res"):
+        x, y = getattr(a, name).reshape(-1), getattr(c, name).reshape(-1)
+        assert bool(((x == y) | (x.isnan() & y.isnan())).all()), name
