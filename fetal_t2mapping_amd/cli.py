@@ -1,6 +1,6 @@
 """CLI and volume driver: the reference's ``run_t2mapping.py`` surface on the MI355X fit.
 
-    python -m fetal_t2mapping_amd.run_t2mapping --path /data/qMRI --csv 2024083017_17510000.csv \
+    python -m fetal_t2mapping_amd.cli --path /data/qMRI --csv 2024083017_17510000.csv \
         --in_vivo --gaussian --lf --sim 1 [--TEs 114 202 299] [--no_prior] [--solver lbfgsb|lm]
 
 Same flags, metadata CSVs, input/output file names and maps as the reference
@@ -47,25 +47,22 @@ def mk_bids_dir(bids_dir, *dirs):
 
 
 def get_img_path(bids_path, acq, type: str = "anat"):
-    """utils/qmri_utils.py:13-33 (same file names, including the width-3 TE field)."""
+    """File naming of utils/qmri_utils.py:13-33: raw images under <prj>/<sub>/<ses>/anat, everything
+    else under <prj>/derivatives/<type>/<sub>/<ses>/anat; recon-type names carry the echo time (width 3)."""
+    sub, ses = acq["sub"], acq["ses"]
+    derived = [acq["prj"], "derivatives", type, sub, ses, "anat"]
     if type == "anat":
-        dirs = [acq["prj"], acq["sub"], acq["ses"], "anat"]
-        name = "_".join([acq["sub"], acq["ses"], acq["run"] + "_T2w.nii.gz"])
+        dirs, stem = [acq["prj"], sub, ses, "anat"], [sub, ses, acq["run"] + "_T2w.nii.gz"]
     elif "t2map" in type:
-        dirs = [acq["prj"], "derivatives", type, acq["sub"], acq["ses"], "anat"]
-        name = "_".join([acq["sub"], acq["ses"], type + ".nii.gz"])
+        dirs, stem = derived, [sub, ses, type + ".nii.gz"]
     elif "recon" in type:
-        dirs = [acq["prj"], "derivatives", type, acq["sub"], acq["ses"], "anat"]
-        if acq["CoilString"] == "Simulation":
-            name = "_".join([acq["sub"], acq["ses"], f"t2-{int(acq['T2']):3}", f"te-{int(acq['EchoTime']):3}",
-                             type + ".nii.gz"])
-        else:
-            name = "_".join([acq["sub"], acq["ses"], f"te-{int(acq['EchoTime'] * 1000):3}", type + ".nii.gz"])
+        simulated = acq["CoilString"] == "Simulation"
+        te_field = f"te-{int(acq['EchoTime'] if simulated else acq['EchoTime'] * 1000):3}"
+        dirs, stem = derived, [sub, ses] + ([f"t2-{int(acq['T2']):3}"] if simulated else []) + [te_field, type + ".nii.gz"]
     else:
-        dirs = [acq["prj"], "derivatives", type, acq["sub"], acq["ses"], "anat"]
-        name = "_".join([acq["sub"], acq["ses"], acq["run"], "T2w", type + ".nii.gz"])
+        dirs, stem = derived, [sub, ses, acq["run"], "T2w", type + ".nii.gz"]
     mk_bids_dir(bids_path, *dirs)
-    return os.path.join(os.path.join(bids_path, *dirs), name)
+    return os.path.join(bids_path, *dirs, "_".join(stem))
 
 
 def set_metadata(csv_path, csvs, low_field):
@@ -185,31 +182,36 @@ def process_t2maps(metadata, bids_path, TEs, fit, fit_params, phantom, low_field
                 save_phantom_csv(t2_map, k_map, sigma_map, label, id_, gt_, bids_path, acq, t2map_dirname, sim, fit)
 
 
+_EXCLUSIVE_GROUPS = (
+    (("in_vivo", "in vivo subject data"),
+     ("in_vitro", "NIST phantom, full maps"),
+     ("in_vitro_fast", "NIST phantom, labelled vials only")),
+    (("gaussian", "2-parameter least squares  k*exp(-TE/T2)"),
+     ("gaussian_rician", "3-parameter least squares  sqrt(k^2 exp(-2TE/T2) + sigma^2)"),
+     ("rician", "3-parameter Rician likelihood")),
+    (("lf", "0.55 T tables and default echo times"),
+     ("hf", "1.5 T tables and default echo times")),
+)
+
+
 def parse_arguments(argv=None):
-    """run_t2mapping.py:483-518 plus --solver / --precision / --device."""
-    p = argparse.ArgumentParser(description="T2 Mapping Parser (MI355X)", formatter_class=argparse.RawTextHelpFormatter)
-    p.add_argument("--path", type=str, required=True, help="Path to general directory ../qMRI/")
-    p.add_argument("--csv", type=str, nargs="+", required=True, help="Name of one or more metadata CSV log files")
-    g = p.add_mutually_exclusive_group(required=True)
-    g.add_argument("--in_vivo", action="store_true", help="Process in vivo data")
-    g.add_argument("--in_vitro", action="store_true", help="Process NIST Phantom data and generate full map")
-    g.add_argument("--in_vitro_fast", action="store_true", help="Process NIST Phantom data only at ROI")
-    g = p.add_mutually_exclusive_group(required=True)
-    g.add_argument("--gaussian", action="store_true", help="T2 fit under gaussian noise assumption")
-    g.add_argument("--gaussian_rician", action="store_true", help="T2 fit under gaussian-rician noise assumption")
-    g.add_argument("--rician", action="store_true", help="T2 fit under rician noise assumption")
-    g = p.add_mutually_exclusive_group(required=True)
-    g.add_argument("--lf", action="store_true", help="Process low-field 0.55 T data")
-    g.add_argument("--hf", action="store_true", help="Process high-field 1.5 T data")
-    p.add_argument("--sim", type=str, required=True, help="T2 fitting ID (can be a description or a simple int)")
-    p.add_argument("--TEs", nargs="+", type=int, help="List of TEs to fit\n   default low-field: [114,202,299]\n"
-                                                      "   default high-field: [115,202,299]")
-    p.add_argument("--no_prior", action="store_true", default=False, help="If set, will not restrict M0 bounds")
-    p.add_argument("--norm", action="store_true", default=False, help="If set, will normalize T2w data")
+    """Flag set of run_t2mapping.py:483-518 (three required one-of groups, --sim, --TEs, --no_prior,
+    --norm) plus --solver / --precision / --device."""
+    p = argparse.ArgumentParser(prog="fetal_t2mapping_amd.cli", description="voxel-wise T2 mapping on an MI355X")
+    p.add_argument("--path", required=True, help="root of the qMRI tree (contains projects/ and dicom/logs/)")
+    p.add_argument("--csv", nargs="+", required=True, help="metadata log CSV file name(s) under dicom/logs/")
+    for group in _EXCLUSIVE_GROUPS:
+        g = p.add_mutually_exclusive_group(required=True)
+        for flag, text in group:
+            g.add_argument("--" + flag, action="store_true", help=text)
+    p.add_argument("--sim", required=True, help="identifier written into the output file names")
+    p.add_argument("--TEs", nargs="+", type=int, help="echo times [ms] to fit (default 114/115, 202, 299)")
+    p.add_argument("--no_prior", action="store_true", help="k >= S(TE0) instead of the table's lower bound")
+    p.add_argument("--norm", action="store_true", help="divide each voxel's samples by their maximum")
     p.add_argument("--solver", choices=["lbfgsb", "lm"], default="lbfgsb",
                    help="lbfgsb: the reference's solver and stop rules (default); lm: converged bounded LM")
     p.add_argument("--precision", choices=["f64", "f32"], default="f64", help="arithmetic of the lm solver")
-    p.add_argument("--device", type=int, default=0)
+    p.add_argument("--device", type=int, default=0, help="HIP device ordinal")
     return p.parse_args(argv)
 
 

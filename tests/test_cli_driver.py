@@ -13,7 +13,7 @@ from oracle import t2fit_oracle as O
 
 
 def _subject(tmp_path, d):
-    from fetal_t2mapping_amd import run_t2mapping as R
+    from fetal_t2mapping_amd import cli as R
 
     bids = str(tmp_path / "projects") + "/"
     os.makedirs(os.path.join(bids, "prj-900"))
@@ -40,7 +40,7 @@ def _oracle_fit_subject(vols, masks, keep, te_eff, fit, fit_params, prior, norm,
 
 
 def test_process_t2maps_plumbing_matches_reference_run(tmp_path, monkeypatch):
-    from fetal_t2mapping_amd import run_t2mapping as R
+    from fetal_t2mapping_amd import cli as R
 
     sitk = fake_sitk.install()
     d = np.load(os.path.join(GOLDEN, "volume_lf_gaussian_noprior.npz"))
@@ -59,7 +59,7 @@ def test_process_t2maps_plumbing_matches_reference_run(tmp_path, monkeypatch):
 
 
 def test_cli_flags_and_tables():
-    from fetal_t2mapping_amd import run_t2mapping as R
+    from fetal_t2mapping_amd import cli as R
 
     with pytest.raises(SystemExit):
         R.parse_arguments(["--path", "p", "--csv", "c.csv", "--in_vivo", "--gaussian", "--rician", "--lf", "--sim", "1"])
@@ -78,7 +78,7 @@ def test_cli_flags_and_tables():
 
 
 def test_missing_te_is_skipped(tmp_path, monkeypatch, capsys):
-    from fetal_t2mapping_amd import run_t2mapping as R
+    from fetal_t2mapping_amd import cli as R
 
     sitk = fake_sitk.install()
     d = np.load(os.path.join(GOLDEN, "volume_lf_gaussian_noprior.npz"))

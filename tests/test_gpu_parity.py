@@ -276,7 +276,7 @@ def test_cli_driver_on_device(t2, tmp_path):
     import pandas as pd
 
     import fake_sitk
-    from fetal_t2mapping_amd import run_t2mapping as R
+    from fetal_t2mapping_amd import cli as R
 
     sitk = fake_sitk.install()
     d = np.load(os.path.join(GOLDEN, "volume_lf_gaussian_noprior.npz"))
