@@ -154,55 +154,8 @@ struct ObjCtx {
   T2_HD float sample(int i) const { return y[i]; }
 };
 
-// mean squared residual, 2-parameter model (run_t2mapping.py:141-147)
-T2_HD double obj_gauss(const ObjCtx& c, double k, double t2) {
-  const int n = c.P->n_te;
-  double s = 0.0;
-  for (int i = 0; i < n; ++i) {
-    double r = (double)c.sample(i) - k * t2_exp(-c.P->te[i] / t2);
-    s += r * r;
-  }
-  return s / n;
-}
-
-// mean squared residual, 3-parameter noise-floor model (run_t2mapping.py:149-155)
-T2_HD double obj_gauss_rician(const ObjCtx& c, double k, double t2, double sg) {
-  const int n = c.P->n_te;
-  const double k2 = k * k, s2 = sg * sg;
-  double s = 0.0;
-  for (int i = 0; i < n; ++i) {
-    double r = (double)c.sample(i) - t2_sqrt(k2 * t2_exp(-2.0 * c.P->te[i] / t2) + s2);
-    s += r * r;
-  }
-  return s / n;
-}
-
-// Rician negative log-likelihood (run_t2mapping.py:157-177).  The reference takes log(signal) and
-// signal**2 in the samples' float32 before promoting, reproduced here.
-T2_HD double obj_rician(const ObjCtx& c, double k, double t2, double sg) {
-  const int n = c.P->n_te;
-  const double s2 = sg * sg;
-  const double ls2 = t2_log(s2);
-  double ll = 0.0;
-  for (int i = 0; i < n; ++i) {
-    const float yf = c.sample(i);
-    const double m = k * t2_exp(-c.P->te[i] / t2);
-    const double x = (m * (double)yf) / s2;
-    const double a = (double)logf(yf) - ls2;
-    const double b = ((double)(yf * yf) + m * m) / (2.0 * s2);
-    const double d = (x < 0 ? -x : x) + t2_log(t2_i0e(x));
-    ll += (a - b) + d;
-  }
-  return -ll;
-}
-
-T2_HD double objective(const ObjCtx& c, const double* x) {
-  switch (c.P->model) {
-    case T2FIT_MODEL_GAUSSIAN: return obj_gauss(c, x[0], x[1]);
-    case T2FIT_MODEL_GAUSSIAN_RICIAN: return obj_gauss_rician(c, x[0], x[1], x[2]);
-    default: return obj_rician(c, x[0], x[1], x[2]);
-  }
-}
+// (the objectives themselves live with the solver that evaluates them: t2fit_lbfgsb.h ObjTerm / eval(),
+// t2fit_lm.h lm_eval())
 
 T2_HD int n_params(int model) { return model == T2FIT_MODEL_GAUSSIAN ? 2 : 3; }
 

@@ -160,11 +160,7 @@ struct LmLane {
     for (int j = 0; j < 3; ++j) x0q[j] = qn[j];
     stage = 0;
     T ks, Rs;
-#if defined(T2_ABLATE_SEED)
-    if (false) {
-#else
     if (loglinear_seed<T>(c, ks, Rs)) {
-#endif
       qn[0] = t2_clip(NP == 3 ? ks * ks : ks, lo[0], hi[0]);
       qn[1] = t2_clip(Rs, lo[1], hi[1]);
       if (NP == 3) {
