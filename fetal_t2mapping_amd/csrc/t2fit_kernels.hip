@@ -143,12 +143,14 @@ __global__ __launch_bounds__(kBlock) void fit_volume_kernel(const LaneParams P, 
 // Persistent form of the reference-trajectory fit.  The number of objective evaluations per voxel
 // varies 4..200 (line searches), so with one voxel per lane a wave waits for its slowest voxel
 // (measured lane efficiency 0.53).  Here a wave keeps all 64 lanes busy instead: waves pull chunks
-// of kChunk consecutive voxels from a global atomic counter, zero-fill the masked-out ones, queue
+// of kChunk (256, or 64 for small volumes) consecutive voxels from a global atomic counter, zero-fill the masked-out ones, queue
 // the active ones in LDS, and every lane that finishes a voxel pops the next one.  The loop body is
 // one objective+gradient evaluation (uniform, expensive) followed by the lane's solver advance
 // (divergent, cheap); the wave leaves when a __ballot shows no lane has work and the queue is dry.
-constexpr int kChunk = 256;
-constexpr int kQueueCap = 64 + kChunk;
+constexpr int kChunkLarge = 256;  // voxels a wave takes from the global queue at a time
+constexpr int kChunkSmall = 64;   // small volumes (phantoms): more, smaller chunks so that every wave gets work
+constexpr int64_t kSmallVolume = 1 << 21;
+constexpr int kQueueCap = 64 + kChunkLarge;
 
 // what the persistent kernel needs to know about a resumable lane solver
 template <int MODEL> struct LbfgsbLane {
@@ -170,7 +172,7 @@ template <typename T, int NPAR> struct LmLaneAdaptor {
   __device__ static void result(const Solver& s, const ObjCtx& c, LaneResult& r) { s.result(c, r); }
 };
 
-template <class A>
+template <class A, int kChunk>
 __global__ __launch_bounds__(kBlock) void fit_persistent_kernel(const LaneParams P,
                                                                        const float* __restrict__ echoes, int layout,
                                                                        const uint8_t* __restrict__ mask, int64_t n_vox,
@@ -471,7 +473,7 @@ template <class A>
 hipError_t launch_persistent(unsigned grid, size_t lds_samples, hipStream_t st, const LaneParams& P,
                              const float* echoes, int layout, const uint8_t* mask, int64_t n_vox, const DevMaps& dm,
                              unsigned long long* counter) {
-  auto kern = fit_persistent_kernel<A>;
+  auto kern = n_vox <= kSmallVolume ? fit_persistent_kernel<A, kChunkSmall> : fit_persistent_kernel<A, kChunkLarge>;
   const size_t lds = ((lds_samples / sizeof(float) + 1) & ~(size_t)1) * sizeof(float) +
                      (size_t)A::kHistDoubles * kBlock * sizeof(double) +
                      (size_t)(kBlock / 64) * kQueueCap * sizeof(uint32_t);
@@ -525,6 +527,7 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
   }
   if (persistent) {
     // one workgroup per CU slot; not required to be co-resident (work comes from an atomic queue)
+    const int kChunk = n_vox <= kSmallVolume ? kChunkSmall : kChunkLarge;
     const int64_t chunks = (n_vox + kChunk - 1) / kChunk;
     const unsigned pgrid = (unsigned)std::min<int64_t>((chunks + 3) / 4, g_persistent_blocks);
     hipError_t pe;
