@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_TE = 32
 
 OK, E_INVALID, E_HIP, E_BOUNDS = 0, -1, -2, -3
@@ -38,6 +38,7 @@ class T2FitMaps(C.Structure):
     _fields_ = [
         ("t2", C.c_void_p), ("k", C.c_void_p), ("sigma", C.c_void_p), ("res", C.c_void_p),
         ("r2", C.c_void_p), ("fun", C.c_void_p), ("nit", C.c_void_p), ("status", C.c_void_p),
+        ("t2_se", C.c_void_p),
     ]
 
 

@@ -29,7 +29,7 @@ inline LaneParams make_lane_params(const t2fit_config& c) {
 }
 
 struct LaneOutputs {
-  float t2, k, sigma, res, r2, fun;
+  float t2, k, sigma, res, r2, fun, se;
   int32_t nit;
   uint8_t status;
 };
@@ -127,9 +127,53 @@ T2_HD float r_squared(const ObjCtx& c, double k, double t2, double sg) {
   return (float)(1.0 - ss_res / ss_tot);
 }
 
+// Standard error of T2 from the Gauss-Newton covariance s^2 (J^T J)^-1 at (k, T2, sigma), with
+// s^2 = SS_res / (nTE - n_par).  Extension (BASELINE.json config 3 asks for CI maps, the reference has
+// none): 95 % confidence interval = T2 +- 1.96 * this.  NaN when under-determined or singular.
+T2_HD float t2_std_error(const ObjCtx& c, double k, double t2, double sg) {
+  const LaneParams& P = *c.P;
+  const int n = P.n_te;
+  const bool sq = P.model == T2FIT_MODEL_GAUSSIAN_RICIAN;
+  const int np = P.model == T2FIT_MODEL_GAUSSIAN ? 2 : 3;
+  if (n <= np) return NAN;
+  double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0, ss = 0;
+  for (int i = 0; i < n; ++i) {
+    const double t = P.te[i];
+    const double E = t2_exp(-t / t2);
+    double m, jk, jt, js;
+    if (sq) {
+      m = t2_sqrt(k * k * E * E + sg * sg);
+      jk = k * E * E / m;
+      jt = k * k * E * E * (t / (t2 * t2)) / m;
+      js = sg / m;
+    } else {
+      m = k * E;
+      jk = E;
+      jt = m * t / (t2 * t2);
+      js = 0.0;
+    }
+    const double r = (double)c.sample(i) - m;
+    ss += r * r;
+    a00 += jk * jk; a01 += jk * jt; a02 += jk * js; a11 += jt * jt; a12 += jt * js; a22 += js * js;
+  }
+  const double s2 = ss / (n - np);
+  double var;
+  if (sq) {
+    // [(J^T J)^-1]_{11} = cofactor / determinant of the symmetric 3x3
+    const double det = a00 * (a11 * a22 - a12 * a12) - a01 * (a01 * a22 - a12 * a02) + a02 * (a01 * a12 - a11 * a02);
+    var = s2 * (a00 * a22 - a02 * a02) / det;
+  } else if (np == 3) {
+    // Rician likelihood model: sigma is not a parameter of the mean model; covariance over (k, T2)
+    var = s2 * a00 / (a00 * a11 - a01 * a01);
+  } else {
+    var = s2 * a00 / (a00 * a11 - a01 * a01);
+  }
+  return var > 0.0 ? (float)t2_sqrt(var) : NAN;
+}
+
 // Epilogue: float32 map values (run_t2mapping.py:456-458 casts), then the residual map and the
 // optional R^2 evaluated from those float32 maps (utils/t2map_utils.py:62-89).
-T2_HD void lane_epilogue(const ObjCtx& c, const LaneResult& r, LaneOutputs& o, bool want_r2) {
+T2_HD void lane_epilogue(const ObjCtx& c, const LaneResult& r, LaneOutputs& o, bool want_r2, bool want_se) {
   o.k = (float)r.x[0];
   o.t2 = (float)r.x[1];
   o.sigma = (float)r.x[2];
@@ -138,6 +182,7 @@ T2_HD void lane_epilogue(const ObjCtx& c, const LaneResult& r, LaneOutputs& o, b
   o.status = r.status;
   o.res = residual_mean(c, o.k, o.t2, o.sigma);
   o.r2 = want_r2 ? r_squared(c, (double)o.k, (double)o.t2, (double)o.sigma) : 0.0f;
+  o.se = want_se ? t2_std_error(c, (double)o.k, (double)o.t2, (double)o.sigma) : 0.0f;
 }
 
 }  // namespace t2fit

@@ -50,7 +50,7 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 struct DevMaps {
-  float *t2, *k, *sigma, *res, *r2, *fun;
+  float *t2, *k, *sigma, *res, *r2, *fun, *se;
   int32_t* nit;
   uint8_t* status;
   double* xd;    // optional: float64 parameters, 3 per voxel (voxel seam)
@@ -85,6 +85,7 @@ __device__ __forceinline__ void store_masked(const DevMaps& m, int64_t v) {
   // zeros outside the mask (run_t2mapping.py:415-418)
   m.t2[v] = 0.0f; m.k[v] = 0.0f; m.sigma[v] = 0.0f; m.res[v] = 0.0f;
   if (m.r2) m.r2[v] = 0.0f;
+  if (m.se) m.se[v] = 0.0f;
   if (m.fun) m.fun[v] = 0.0f;
   if (m.nit) m.nit[v] = 0;
   if (m.status) m.status[v] = T2FIT_ST_MASKED;
@@ -95,6 +96,7 @@ __device__ __forceinline__ void store_masked(const DevMaps& m, int64_t v) {
 __device__ __forceinline__ void store_result(const DevMaps& m, int64_t v, const LaneOutputs& o, const LaneResult& r) {
   m.t2[v] = o.t2; m.k[v] = o.k; m.sigma[v] = o.sigma; m.res[v] = o.res;
   if (m.r2) m.r2[v] = o.r2;
+  if (m.se) m.se[v] = o.se;
   if (m.fun) m.fun[v] = o.fun;
   if (m.nit) m.nit[v] = o.nit;
   if (m.status) m.status[v] = o.status;
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void fit_volume_kernel(const LaneParams P, 
   LaneResult r;
   fit_lane_t<SOLVER, PREC, MODEL>(P, c, finite, y0_raw, r);
   LaneOutputs o;
-  lane_epilogue(c, r, o, m.r2 != nullptr);
+  lane_epilogue(c, r, o, m.r2 != nullptr, m.se != nullptr);
   store_result(m, v, o, r);
 }
 
@@ -343,7 +345,8 @@ __global__ __launch_bounds__(kBlock) void residuals_kernel(const LaneParams P, c
                                                            int layout, const uint8_t* __restrict__ mask,
                                                            int64_t n_vox, const float* __restrict__ t2,
                                                            const float* __restrict__ k,
-                                                           const float* __restrict__ sigma, float* res, float* r2) {
+                                                           const float* __restrict__ sigma, float* res, float* r2,
+                                                           float* se) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x;
   const int64_t base = (int64_t)blockIdx.x * kBlock;
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(kBlock) void residuals_kernel(const LaneParams P, c
   const bool active = in_range && (mask == nullptr || mask[v] != 0);
   stage_echoes(lds, echoes, layout, P.n_te, n_vox, base, active);
   if (!in_range) return;
-  float out = 0.0f, out2 = 0.0f;
+  float out = 0.0f, out2 = 0.0f, out3 = 0.0f;
   if (active) {
     bool finite;
     float y0_raw;
@@ -360,9 +363,11 @@ __global__ __launch_bounds__(kBlock) void residuals_kernel(const LaneParams P, c
     const float kv = k[v], tv = t2[v], sv = sigma ? sigma[v] : 0.0f;
     out = residual_mean(c, kv, tv, sv);
     if (r2) out2 = r_squared(c, (double)kv, (double)tv, (double)sv);
+    if (se) out3 = t2_std_error(c, (double)kv, (double)tv, (double)sv);
   }
   res[v] = out;
   if (r2) r2[v] = out2;
+  if (se) se[v] = out3;
 }
 
 // ---- union mask + ordered flat indices (run_t2mapping.py:383-384,412,421) ----------------------
@@ -550,7 +555,7 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
       g_ev_valid = true;
     }
     hipLaunchKernelGGL(residuals_kernel, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox,
-                       (const float*)dm.t2, (const float*)dm.k, (const float*)dm.sigma, dm.res, dm.r2);
+                       (const float*)dm.t2, (const float*)dm.k, (const float*)dm.sigma, dm.res, dm.r2, dm.se);
   } else {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox, dm);
   }
@@ -618,7 +623,8 @@ int t2fit_volume_dev(const t2fit_config* cfg, const float* echoes_dev, int layou
   if (rc != T2FIT_OK) return rc;
   if (!maps || !maps->t2 || !maps->k || !maps->sigma || !maps->res)
     return fail(T2FIT_E_INVALID, "maps->t2/k/sigma/res must be non-NULL");
-  DevMaps dm{maps->t2, maps->k, maps->sigma, maps->res, maps->r2, maps->fun, maps->nit, maps->status, nullptr, nullptr};
+  DevMaps dm{maps->t2, maps->k, maps->sigma, maps->res, maps->r2, maps->fun, maps->t2_se, maps->nit, maps->status,
+             nullptr, nullptr};
   return launch_fit(cfg, echoes_dev, layout, mask_dev, n_vox, dm, (hipStream_t)stream);
 }
 
@@ -633,10 +639,10 @@ int t2fit_volume_host(const t2fit_config* cfg, const float* echoes, int layout, 
   hipStream_t st;
   T2_HIP(hipStreamCreate(&st));
   const size_t nb_e = (size_t)n_vox * cfg->n_te * sizeof(float);
-  // one allocation: echoes | 6 float maps | nit | mask | status
+  // one allocation: echoes | 7 float maps | nit | mask | status
   const size_t off_maps = (nb_e + 255) & ~(size_t)255;
   const size_t map_b = (((size_t)n_vox * 4) + 255) & ~(size_t)255;
-  const size_t off_nit = off_maps + 6 * map_b;
+  const size_t off_nit = off_maps + 7 * map_b;
   const size_t off_mask = off_nit + map_b;
   const size_t byte_b = ((size_t)n_vox + 255) & ~(size_t)255;
   const size_t off_status = off_mask + byte_b;
@@ -662,15 +668,16 @@ int t2fit_volume_host(const t2fit_config* cfg, const float* echoes, int layout, 
     dmask = (uint8_t*)(buf + off_mask);
     T2_HIP_C(hipMemcpyAsync(dmask, mask, (size_t)n_vox, hipMemcpyHostToDevice, st));
   }
-  float* fm[6];
-  for (int j = 0; j < 6; ++j) fm[j] = (float*)(buf + off_maps + j * map_b);
+  float* fm[7];
+  for (int j = 0; j < 7; ++j) fm[j] = (float*)(buf + off_maps + j * map_b);
   DevMaps dm{fm[0], fm[1], fm[2], fm[3], maps->r2 ? fm[4] : nullptr, maps->fun ? fm[5] : nullptr,
+             maps->t2_se ? fm[6] : nullptr,
              maps->nit ? (int32_t*)(buf + off_nit) : nullptr, maps->status ? (uint8_t*)(buf + off_status) : nullptr,
              nullptr, nullptr};
   rc = launch_fit(cfg, (const float*)buf, layout, dmask, n_vox, dm, st);
   if (rc != T2FIT_OK) { cleanup(); return rc; }
-  float* host_f[6] = {maps->t2, maps->k, maps->sigma, maps->res, maps->r2, maps->fun};
-  for (int j = 0; j < 6; ++j)
+  float* host_f[7] = {maps->t2, maps->k, maps->sigma, maps->res, maps->r2, maps->fun, maps->t2_se};
+  for (int j = 0; j < 7; ++j)
     if (host_f[j]) T2_HIP_C(hipMemcpyAsync(host_f[j], fm[j], (size_t)n_vox * 4, hipMemcpyDeviceToHost, st));
   if (maps->nit) T2_HIP_C(hipMemcpyAsync(maps->nit, buf + off_nit, (size_t)n_vox * 4, hipMemcpyDeviceToHost, st));
   if (maps->status) T2_HIP_C(hipMemcpyAsync(maps->status, buf + off_status, (size_t)n_vox, hipMemcpyDeviceToHost, st));
@@ -709,7 +716,7 @@ int t2fit_voxels_host(const t2fit_config* cfg, const float* echoes, int layout, 
   auto cleanup = [&]() { (void)hipFree(buf); };
   T2_HIP_C(hipMemcpy(buf, rows.data(), nb_e, hipMemcpyHostToDevice));
   DevMaps dm{(float*)(buf + off_maps), (float*)(buf + off_maps + map_b), (float*)(buf + off_maps + 2 * map_b),
-             (float*)(buf + off_maps + 3 * map_b), nullptr, nullptr, (int32_t*)(buf + off_nit),
+             (float*)(buf + off_maps + 3 * map_b), nullptr, nullptr, nullptr, (int32_t*)(buf + off_nit),
              (uint8_t*)(buf + off_status), (double*)(buf + off_x), (double*)(buf + off_f)};
   rc = launch_fit(cfg, (const float*)buf, T2FIT_LAYOUT_VOXEL_MAJOR, nullptr, n_idx, dm, nullptr);
   if (rc != T2FIT_OK) { cleanup(); return rc; }
@@ -761,7 +768,7 @@ int t2fit_residuals_dev(const t2fit_config* cfg, const float* echoes_dev, int la
   const unsigned grid = (unsigned)((n_vox + kBlock - 1) / kBlock);
   const size_t lds = (size_t)cfg->n_te * kLdsStride * sizeof(float);
   hipLaunchKernelGGL(residuals_kernel, dim3(grid), dim3(kBlock), lds, (hipStream_t)stream, P, echoes_dev, layout,
-                     mask_dev, n_vox, t2, k, sigma, res, (float*)nullptr);
+                     mask_dev, n_vox, t2, k, sigma, res, (float*)nullptr, (float*)nullptr);
   T2_HIP(hipGetLastError());
   return T2FIT_OK;
 }

@@ -168,6 +168,7 @@ class T2Maps:
     fun: Optional[object] = None
     nit: Optional[object] = None
     status: Optional[object] = None
+    t2_se: Optional[object] = None  # standard error of T2 (extension; 95 % CI = T2 +- 1.96 t2_se)
 
     def success(self):
         """scipy ``result.success`` per voxel (False outside the mask)."""
@@ -216,10 +217,10 @@ def fit_volume(echoes, mask, TEeffs, fit, fit_params, prior=True, norm=False, *,
             f32 = lambda: torch.empty(spatial, dtype=torch.float32, device=dev)  # noqa: E731
             out = T2Maps(f32(), f32(), f32(), f32())
             if extras:
-                out.r2, out.fun = f32(), f32()
+                out.r2, out.fun, out.t2_se = f32(), f32(), f32()
                 out.nit = torch.empty(spatial, dtype=torch.int32, device=dev)
                 out.status = torch.empty(spatial, dtype=torch.uint8, device=dev)
-        for name in ("t2", "k", "sigma", "res", "r2", "fun", "nit", "status"):
+        for name in ("t2", "k", "sigma", "res", "r2", "fun", "nit", "status", "t2_se"):
             t = getattr(out, name)
             setattr(maps, name, None if t is None else t.data_ptr())
         with torch.cuda.device(dev):
@@ -236,8 +237,8 @@ def fit_volume(echoes, mask, TEeffs, fit, fit_params, prior=True, norm=False, *,
     out = T2Maps(f32(), f32(), f32(), f32())
     out.status = np.empty(spatial, np.uint8)
     if extras:
-        out.r2, out.fun, out.nit = f32(), f32(), np.empty(spatial, np.int32)
-    for name in ("t2", "k", "sigma", "res", "r2", "fun", "nit", "status"):
+        out.r2, out.fun, out.nit, out.t2_se = f32(), f32(), np.empty(spatial, np.int32), f32()
+    for name in ("t2", "k", "sigma", "res", "r2", "fun", "nit", "status", "t2_se"):
         a = getattr(out, name)
         setattr(maps, name, None if a is None else a.ctypes.data)
     check(lib.t2fit_volume_host(C.byref(cfg), e.ctypes.data, lay, None if m is None else m.ctypes.data, n,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define T2FIT_ABI_VERSION 1
+#define T2FIT_ABI_VERSION 2
 #define T2FIT_MAX_TE 32
 
 /* error codes */
@@ -105,6 +105,10 @@ typedef struct t2fit_maps {
   float *fun;      /* optional: final objective value (result.fun, :293)                        */
   int32_t *nit;    /* optional: iterations (result.nit, :292)                                   */
   uint8_t *status; /* optional: T2FIT_ST_*                                                      */
+  float *t2_se;    /* optional: standard error of T2 [ms] from the Gauss-Newton covariance
+                      s^2 (J^T J)^-1, s^2 = SS_res / (nTE - n_par), J = d model / d (k, T2, sigma) at the
+                      float32 map values; NaN when nTE <= n_par or J^T J is singular.  A 95 % confidence
+                      interval is T2 +- 1.96 t2_se.  Extension: the reference has no CI map.            */
 } t2fit_maps;
 
 /* Fill *cfg with the reference table for (model, low_field): x0, bounds, ftol/gtol/maxls from

@@ -29,7 +29,7 @@ extern "C" int hostsim_fit_rows(const t2fit_config* cfg, const float* rows, int6
     LaneResult r;
     fit_lane(P, c, finite, y0_raw, r);
     LaneOutputs o;
-    lane_epilogue(c, r, o, r2 != nullptr);
+    lane_epilogue(c, r, o, r2 != nullptr, false);
     for (int j = 0; j < 3; ++j) x[v * 3 + j] = r.x[j];
     fun[v] = r.fun;
     nit[v] = r.nit;

@@ -452,3 +452,32 @@ def test_full_size_properties_256cubed(t2):
     for name in ("t2", "k", "sigma", "res"):
         x, y = getattr(a, name).reshape(-1), getattr(c, name).reshape(-1)
         assert bool(((x == y) | (x.isnan() & y.isnan())).all()), name
+
+
+def test_t2_standard_error_map_definition(t2):
+    """CI extension (BASELINE.json config 3 asks for CI maps; the reference has none, so this is
+    checked against its definition only): se(T2) = sqrt(s^2 [(J^T J)^-1]_T2,T2), s^2 = SS_res/(n - p)."""
+    from fetal_t2mapping_amd import synth
+
+    echoes, mask, te = synth.brain_volume((3, 10, 24), 8, seed=5)
+    for fit, n_par in (("gaussian", 2), ("gaussian_rician", 3)):
+        m = t2.fit_volume(echoes, mask, te, fit, t2.fit_table(fit, True), solver="lm", extras=True)
+        idx = np.flatnonzero(mask.reshape(-1))
+        y = echoes.reshape(len(te), -1)[:, idx].T.astype(np.float64)
+        k, T2, sg = (np.asarray(getattr(m, n), np.float64).reshape(-1)[idx] for n in ("k", "t2", "sigma"))
+        E = np.exp(-te[None] / T2[:, None])
+        if fit == "gaussian":
+            mod = k[:, None] * E
+            J = np.stack([E, mod * te[None] / T2[:, None] ** 2], axis=2)
+        else:
+            mod = np.sqrt(k[:, None] ** 2 * E ** 2 + sg[:, None] ** 2)
+            J = np.stack([k[:, None] * E ** 2 / mod, k[:, None] ** 2 * E ** 2 * te[None] / T2[:, None] ** 2 / mod,
+                          sg[:, None] / mod], axis=2)
+        s2 = ((y - mod) ** 2).sum(1) / (len(te) - n_par)
+        cov = np.linalg.inv(np.einsum("vti,vtj->vij", J, J)) * s2[:, None, None]
+        want = np.sqrt(cov[:, 1, 1])
+        got = m.t2_se.reshape(-1)[idx].astype(np.float64)
+        ok = np.isfinite(want) & np.isfinite(got)
+        assert ok.mean() > 0.95
+        assert np.allclose(got[ok], want[ok], rtol=2e-3, atol=1e-4)
+        assert np.all(m.t2_se[mask == 0] == 0)
