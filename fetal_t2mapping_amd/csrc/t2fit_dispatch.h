@@ -2,8 +2,7 @@
 // Mirrors the control flow of fit_voxel (run_t2mapping.py:237-312) for a single lane.
 //
 // fit_lane_t<SOLVER, PREC, MODEL> is the compile-time specialised lane body each kernel
-// instantiation uses (so its register allocation covers one path only); fit_lane() is the runtime
-// switch used by the host-side lane simulator in tests/.
+// instantiation uses, so its register allocation covers one path only.
 #pragma once
 
 #include "t2fit_lane.h"
@@ -87,23 +86,6 @@ T2_HD void fit_lane_t(const LaneParams& P, const ObjCtx& c, bool finite, float y
     else lm_solve<double, NP>(c, lb, ub, r);
   } else {
     lbfgsb_solve<MODEL>(c, lb, ub, r);
-  }
-}
-
-// runtime switch (host simulator); the kernels pick the instantiation at launch time instead
-T2_HD void fit_lane(const LaneParams& P, const ObjCtx& c, bool finite, float y0_raw, LaneResult& r) {
-  if (P.solver == T2FIT_SOLVER_LM) {
-    if (P.precision == T2FIT_PREC_F32) {
-      if (P.model == T2FIT_MODEL_GAUSSIAN) fit_lane_t<T2FIT_SOLVER_LM, T2FIT_PREC_F32, T2FIT_MODEL_GAUSSIAN>(P, c, finite, y0_raw, r);
-      else fit_lane_t<T2FIT_SOLVER_LM, T2FIT_PREC_F32, T2FIT_MODEL_GAUSSIAN_RICIAN>(P, c, finite, y0_raw, r);
-    } else {
-      if (P.model == T2FIT_MODEL_GAUSSIAN) fit_lane_t<T2FIT_SOLVER_LM, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN>(P, c, finite, y0_raw, r);
-      else fit_lane_t<T2FIT_SOLVER_LM, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN_RICIAN>(P, c, finite, y0_raw, r);
-    }
-  } else {
-    if (P.model == T2FIT_MODEL_GAUSSIAN) fit_lane_t<T2FIT_SOLVER_LBFGSB, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN>(P, c, finite, y0_raw, r);
-    else if (P.model == T2FIT_MODEL_GAUSSIAN_RICIAN) fit_lane_t<T2FIT_SOLVER_LBFGSB, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN_RICIAN>(P, c, finite, y0_raw, r);
-    else fit_lane_t<T2FIT_SOLVER_LBFGSB, T2FIT_PREC_F64, T2FIT_MODEL_RICIAN>(P, c, finite, y0_raw, r);
   }
 }
 
