@@ -124,7 +124,9 @@ int t2fit_device_count(void);
  *   echoes_dev : float32, layout per `layout`
  *   mask_dev   : uint8 [n_vox] (non-zero = fit), or NULL to fit every voxel
  *   maps       : device pointers
- * Asynchronous on `stream`; the caller synchronises. */
+ *   n_vox      : below 2^32 per call (split larger stacks into slabs; voxels are independent)
+ * Asynchronous on `stream`; the caller synchronises.  Two launches: the persistent fit kernel
+ * (t2, k, sigma and the optional per-voxel extras) and a streaming epilogue (res, r2, t2_se). */
 int t2fit_volume_dev(const t2fit_config *cfg, const float *echoes_dev, int layout,
                      const uint8_t *mask_dev, int64_t n_vox, const t2fit_maps *maps, void *stream);
 

@@ -481,3 +481,28 @@ def test_t2_standard_error_map_definition(t2):
         assert ok.mean() > 0.95
         assert np.allclose(got[ok], want[ok], rtol=2e-3, atol=1e-4)
         assert np.all(m.t2_se[mask == 0] == 0)
+
+
+def test_sharded_path_with_rccl_single_rank(t2):
+    """fit_volume_sharded end to end on the device with the RCCL backend (world_size 1 is all one
+    GPU box allows): slab cut, packed maps, all_gather_into_tensor, trim == plain fit_volume.
+    The partition + gather logic for N > 1 is covered on CPU by tests/test_dist_gloo.py."""
+    import torch
+    import torch.distributed as dist
+
+    from fetal_t2mapping_amd import dist as t2dist, synth
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        echoes, mask, te = synth.brain_volume((3, 9, 31), 6, seed=9)
+        table = t2.fit_table("gaussian_rician", True)
+        got = t2dist.fit_volume_sharded(echoes, mask, te, "gaussian_rician", table)
+        torch.cuda.synchronize()
+        want = t2.fit_volume(echoes, mask, te, "gaussian_rician", table)
+        for name in ("t2", "k", "sigma", "res"):
+            assert np.array_equal(getattr(got, name).cpu().numpy(), getattr(want, name), equal_nan=True), name
+    finally:
+        dist.destroy_process_group()
