@@ -50,6 +50,8 @@ SYMBOLS = [
     ("t2fit_volume_dev", C.c_int, [C.POINTER(T2FitConfig), _P, C.c_int, _P, C.c_int64, C.POINTER(T2FitMaps), _P]),
     ("t2fit_volume_host", C.c_int, [C.POINTER(T2FitConfig), _P, C.c_int, _P, C.c_int64, C.POINTER(T2FitMaps), C.c_int]),
     ("t2fit_voxels_host", C.c_int, [C.POINTER(T2FitConfig), _P, C.c_int, C.c_int64, _P, C.c_int64, _P, _P, _P, _P, C.c_int]),
+    ("t2fit_voxels_trace_host", C.c_int, [C.POINTER(T2FitConfig), _P, C.c_int, C.c_int64, _P, C.c_int64, _P, _P, _P, _P,
+                                          C.c_int, _P, _P, C.c_int]),
     ("t2fit_union_mask_dev", C.c_int, [_P, C.c_int, C.c_int64, _P, _P, _P, _P]),
     ("t2fit_residuals_dev", C.c_int, [C.POINTER(T2FitConfig), _P, C.c_int, _P, C.c_int64, _P, _P, _P, _P, _P]),
     ("t2fit_set_timing", C.c_int, [C.c_int]),

@@ -1,15 +1,17 @@
 // t2fit_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the per-voxel T2 fit and the C ABI of
 // include/t2fit.h.  Built with:  hipcc -O3 --offload-arch=gfx950 -shared -fPIC
 //
-// Mapping: one lane per voxel, 256-thread workgroups (4 wave64), grid = ceil(N / 256) >> 256 CUs.
-// HBM layout: echoes (nTE, N) float32 -- lane v of a wave reads echoes[i*N + base + v], so every TE
-// plane read is one fully coalesced 256-byte wave access; each sample is read exactly once and
-// parked in LDS ([nTE][257] floats per workgroup, one column per lane, padded so the
-// voxel-major staging transpose is conflict-free).  The solver then re-reads its column from LDS
-// on every objective evaluation instead of holding nTE samples in VGPRs (nTE is a run-time value).
-// Each map is written once, one dword per lane, coalesced.  Algorithmic HBM traffic per voxel:
-// 4*nTE (samples) + 1 (mask) + 16 (t2,k,sigma,res)  =  49 B at 8 TE.
-// The fit itself is ALU work (exp/sqrt/fma, fp32 or fp64); no MFMA: nothing here is a contraction.
+// Mapping: one lane fits one voxel at a time, 256-thread workgroups (4 wave64).  The fit kernels
+// are persistent: waves pull chunks of consecutive voxels from a global atomic counter and every
+// lane that finishes a voxel takes the next one (fit_persistent_kernel below); the streaming
+// kernels (residual map, mask union) use grid = ceil(N / tile) >> 256 CUs.
+// HBM layout: echoes (nTE, N) float32, TE-major; every sample of a fitted voxel is read once and
+// parked in LDS ([nTE][257] floats per workgroup, one column per lane, padded so the voxel-major
+// staging transpose is conflict-free).  The solver re-reads its column from LDS on every objective
+// evaluation instead of holding nTE samples in VGPRs (nTE is a run-time value).  Each map is
+// written once.  Algorithmic HBM traffic per voxel: 4*nTE (samples) + 1 (mask) + 16 (t2, k, sigma,
+// res) = 49 B at 8 TE.  The fit itself is ALU work (exp/sqrt/div/fma, fp64 or fp32); no MFMA:
+// nothing here is a contraction.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -55,6 +57,9 @@ struct DevMaps {
   uint8_t* status;
   double* xd;    // optional: float64 parameters, 3 per voxel (voxel seam)
   double* fund;  // optional: float64 objective value
+  double* trace = nullptr;         // trace kernels only: [n_vox][trace_cap][4] doubles (k, T2, sigma, f)
+  int32_t* trace_len = nullptr;    //                     iterations recorded per voxel
+  int trace_cap = 0;
 };
 
 // Stage this workgroup's samples into LDS.  TE-major: each lane copies its own column (coalesced
@@ -174,7 +179,7 @@ template <typename T, int NPAR> struct LmLaneAdaptor {
   __device__ static void result(const Solver& s, const ObjCtx& c, LaneResult& r) { s.result(c, r); }
 };
 
-template <class A, int kChunk>
+template <class A, int kChunk, bool kTrace = false>
 __global__ __launch_bounds__(kBlock) void fit_persistent_kernel(const LaneParams P,
                                                                        const float* __restrict__ echoes, int layout,
                                                                        const uint8_t* __restrict__ mask, int64_t n_vox,
@@ -305,6 +310,12 @@ __global__ __launch_bounds__(kBlock) void fit_persistent_kernel(const LaneParams
           store_fit(m, v, r);
           busy = false;
         } else {
+          if constexpr (kTrace) {  // per-iteration trace of this voxel (voxel seam only)
+            c.trace = m.trace + (size_t)v * 4 * m.trace_cap;
+            c.trace_cap = m.trace_cap;
+            c.trace_n = m.trace_len + v;
+            *c.trace_n = 0;
+          }
           A::init(s, c, box_x0, lb, ub, hist);
         }
       }
@@ -478,7 +489,8 @@ template <class A>
 hipError_t launch_persistent(unsigned grid, size_t lds_samples, hipStream_t st, const LaneParams& P,
                              const float* echoes, int layout, const uint8_t* mask, int64_t n_vox, const DevMaps& dm,
                              unsigned long long* counter) {
-  auto kern = n_vox <= kSmallVolume ? fit_persistent_kernel<A, kChunkSmall> : fit_persistent_kernel<A, kChunkLarge>;
+  auto kern = dm.trace ? fit_persistent_kernel<A, kChunkSmall, true>
+                       : (n_vox <= kSmallVolume ? fit_persistent_kernel<A, kChunkSmall> : fit_persistent_kernel<A, kChunkLarge>);
   const size_t lds = ((lds_samples / sizeof(float) + 1) & ~(size_t)1) * sizeof(float) +
                      (size_t)A::kHistDoubles * kBlock * sizeof(double) +
                      (size_t)(kBlock / 64) * kQueueCap * sizeof(uint32_t);
@@ -532,7 +544,7 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
   }
   if (persistent) {
     // one workgroup per CU slot; not required to be co-resident (work comes from an atomic queue)
-    const int kChunk = n_vox <= kSmallVolume ? kChunkSmall : kChunkLarge;
+    const int kChunk = (dm.trace || n_vox <= kSmallVolume) ? kChunkSmall : kChunkLarge;
     const int64_t chunks = (n_vox + kChunk - 1) / kChunk;
     const unsigned pgrid = (unsigned)std::min<int64_t>((chunks + 3) / 4, g_persistent_blocks);
     hipError_t pe;
@@ -686,11 +698,13 @@ int t2fit_volume_host(const t2fit_config* cfg, const float* echoes, int layout, 
   return T2FIT_OK;
 }
 
-int t2fit_voxels_host(const t2fit_config* cfg, const float* echoes, int layout, int64_t n_vox, const int64_t* idx,
-                      int64_t n_idx, double* x, double* fun, int32_t* nit, uint8_t* status, int device) {
+static int voxels_host_impl(const t2fit_config* cfg, const float* echoes, int layout, int64_t n_vox, const int64_t* idx,
+                            int64_t n_idx, double* x, double* fun, int32_t* nit, uint8_t* status, int cap,
+                            double* trace_x, int32_t* trace_len, int device) {
   int rc = check_common(cfg, echoes, layout, n_vox);
   if (rc != T2FIT_OK) return rc;
   if (n_idx < 0 || (n_idx > 0 && (!idx || !x))) return fail(T2FIT_E_INVALID, "idx/x must be non-NULL");
+  if (cap < 0 || (cap > 0 && (!trace_x || !trace_len))) return fail(T2FIT_E_INVALID, "trace buffers must be non-NULL");
   if (n_idx == 0) return T2FIT_OK;
   const int n_te = cfg->n_te;
   // gather the requested rows into a compact voxel-major block on the host
@@ -703,14 +717,17 @@ int t2fit_voxels_host(const t2fit_config* cfg, const float* echoes, int layout, 
           layout == T2FIT_LAYOUT_TE_MAJOR ? echoes[(size_t)i * n_vox + v] : echoes[(size_t)v * n_te + i];
   }
   T2_HIP(hipSetDevice(device));
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const size_t nb_e = rows.size() * sizeof(float);
-  const size_t off_x = (nb_e + 255) & ~(size_t)255;
-  const size_t off_f = off_x + (((size_t)n_idx * 24 + 255) & ~(size_t)255);
-  const size_t off_maps = off_f + (((size_t)n_idx * 8 + 255) & ~(size_t)255);
-  const size_t map_b = (((size_t)n_idx * 4) + 255) & ~(size_t)255;
+  const size_t off_x = pad(nb_e);
+  const size_t off_f = off_x + pad((size_t)n_idx * 24);
+  const size_t off_maps = off_f + pad((size_t)n_idx * 8);
+  const size_t map_b = pad((size_t)n_idx * 4);
   const size_t off_nit = off_maps + 4 * map_b;
   const size_t off_status = off_nit + map_b;
-  const size_t total = off_status + (((size_t)n_idx + 255) & ~(size_t)255);
+  const size_t off_tlen = off_status + pad((size_t)n_idx);
+  const size_t off_trace = off_tlen + map_b;
+  const size_t total = off_trace + pad((size_t)n_idx * cap * 32);
   char* buf = nullptr;
   T2_HIP(hipMalloc((void**)&buf, total));
   auto cleanup = [&]() { (void)hipFree(buf); };
@@ -718,6 +735,12 @@ int t2fit_voxels_host(const t2fit_config* cfg, const float* echoes, int layout, 
   DevMaps dm{(float*)(buf + off_maps), (float*)(buf + off_maps + map_b), (float*)(buf + off_maps + 2 * map_b),
              (float*)(buf + off_maps + 3 * map_b), nullptr, nullptr, nullptr, (int32_t*)(buf + off_nit),
              (uint8_t*)(buf + off_status), (double*)(buf + off_x), (double*)(buf + off_f)};
+  if (cap > 0) {
+    T2_HIP_C(hipMemset(buf + off_tlen, 0, map_b));
+    dm.trace = (double*)(buf + off_trace);
+    dm.trace_len = (int32_t*)(buf + off_tlen);
+    dm.trace_cap = cap;
+  }
   rc = launch_fit(cfg, (const float*)buf, T2FIT_LAYOUT_VOXEL_MAJOR, nullptr, n_idx, dm, nullptr);
   if (rc != T2FIT_OK) { cleanup(); return rc; }
   T2_HIP_C(hipDeviceSynchronize());
@@ -725,8 +748,25 @@ int t2fit_voxels_host(const t2fit_config* cfg, const float* echoes, int layout, 
   if (fun) T2_HIP_C(hipMemcpy(fun, buf + off_f, (size_t)n_idx * 8, hipMemcpyDeviceToHost));
   if (nit) T2_HIP_C(hipMemcpy(nit, buf + off_nit, (size_t)n_idx * 4, hipMemcpyDeviceToHost));
   if (status) T2_HIP_C(hipMemcpy(status, buf + off_status, (size_t)n_idx, hipMemcpyDeviceToHost));
+  if (cap > 0) {
+    T2_HIP_C(hipMemcpy(trace_x, buf + off_trace, (size_t)n_idx * cap * 32, hipMemcpyDeviceToHost));
+    T2_HIP_C(hipMemcpy(trace_len, buf + off_tlen, (size_t)n_idx * 4, hipMemcpyDeviceToHost));
+  }
   cleanup();
   return T2FIT_OK;
+}
+
+int t2fit_voxels_host(const t2fit_config* cfg, const float* echoes, int layout, int64_t n_vox, const int64_t* idx,
+                      int64_t n_idx, double* x, double* fun, int32_t* nit, uint8_t* status, int device) {
+  return voxels_host_impl(cfg, echoes, layout, n_vox, idx, n_idx, x, fun, nit, status, 0, nullptr, nullptr, device);
+}
+
+int t2fit_voxels_trace_host(const t2fit_config* cfg, const float* echoes, int layout, int64_t n_vox,
+                            const int64_t* idx, int64_t n_idx, double* x, double* fun, int32_t* nit, uint8_t* status,
+                            int trace_cap, double* trace, int32_t* trace_len, int device) {
+  if (trace_cap < 1) return fail(T2FIT_E_INVALID, "trace_cap must be >= 1");
+  return voxels_host_impl(cfg, echoes, layout, n_vox, idx, n_idx, x, fun, nit, status, trace_cap, trace, trace_len,
+                          device);
 }
 
 int t2fit_union_mask_dev(const uint8_t* masks_dev, int n_masks, int64_t n_vox, uint8_t* mask_out, int64_t* idx_out,

@@ -148,7 +148,7 @@ T2_HD double t2_i0e(double x) {
 struct ObjCtx {
   const LaneParams* P;
   EchoView y;
-  double* trace = nullptr;  // optional (host simulator only): x, f per iteration, 4 doubles each
+  double* trace = nullptr;  // optional: (k, T2, sigma, f) after each iteration, 4 doubles each
   int trace_cap = 0;
   int* trace_n = nullptr;
   T2_HD float sample(int i) const { return y[i]; }

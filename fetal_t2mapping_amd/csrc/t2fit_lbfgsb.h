@@ -713,12 +713,10 @@ struct Lbfgsb {
       } else {
         // ---- new iterate: stop tests, then the correction pair ----
         ++nit;
-#if !defined(__HIP_DEVICE_COMPILE__)
-        if (c.trace && *c.trace_n < c.trace_cap) {
+        if (c.trace && *c.trace_n < c.trace_cap) {  // what scipy hands to the reference's callback (:180-234)
           double* tr = c.trace + 4 * (*c.trace_n)++;
           tr[0] = x[0]; tr[1] = x[1]; tr[2] = N == 3 ? x[N - 1] : 0.0; tr[3] = f;
         }
-#endif
         sbgnrm = projgr(x, g);
         const double tol = (P.ftol / epsmch) * epsmch;  // factr * epsmch
         if (nit >= P.maxiter || nfev > P.maxfun) {

@@ -233,13 +233,11 @@ struct LmLane {
         nu = T(2);
         for (int j = 0; j < 3; ++j) q[j] = qn[j];
         e = en;
-#if !defined(__HIP_DEVICE_COMPILE__)
         if (c.trace && *c.trace_n < c.trace_cap) {
           double* tr = c.trace + 4 * (*c.trace_n)++;
           tr[0] = NP == 3 ? sqrt((double)q[0]) : (double)q[0]; tr[1] = 1.0 / (double)q[1];
-          tr[2] = (double)lambda; tr[3] = (double)e.f / c.P->n_te;
+          tr[2] = NP == 3 ? sqrt((double)q[2]) : 0.0; tr[3] = (double)e.f / c.P->n_te;
         }
-#endif
         if (rel <= xtol || act <= (T)LmTol<T>::ftiny * e.f) { status = T2FIT_ST_CONVERGED; ++it; return true; }
       } else {
         lambda *= nu;

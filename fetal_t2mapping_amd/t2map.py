@@ -279,24 +279,53 @@ def fit_voxels(indices, fit, fit_params, TEeffs, reshaped_t2w, prior, norm, *, s
     return x[:, :n_par], st == _abi.ST_CONVERGED, nit, fun, st
 
 
-def fit_voxel(voxel, fit, fit_params, TEeffs, reshaped_t2w, prior, norm, **kw):
+def fit_voxels_trace(indices, fit, fit_params, TEeffs, reshaped_t2w, prior, norm, *, trace_cap=64, solver="lbfgsb",
+                     precision="f64", device=0):
+    """``fit_voxels`` plus, per voxel, the reference's ``iteration_info`` (run_t2mapping.py:180-234): a
+    list of ``{'f_val', 'grad_norm': None, 'step_size'}`` dicts, one per iteration (at most ``trace_cap``)."""
+    cfg = make_config(fit, fit_params, TEeffs, prior, norm, solver, precision)
+    lib = require_gpu()
+    data = np.ascontiguousarray(reshaped_t2w, dtype=np.float32)
+    idx = np.ascontiguousarray(np.atleast_1d(indices), dtype=np.int64)
+    m = idx.size
+    x, fun = np.zeros((m, 3)), np.zeros(m)
+    nit, st = np.zeros(m, np.int32), np.zeros(m, np.uint8)
+    tr, tl = np.zeros((m, trace_cap, 4)), np.zeros(m, np.int32)
+    check(lib.t2fit_voxels_trace_host(C.byref(cfg), data.ctypes.data, _abi.LAYOUT_VOXEL_MAJOR, data.shape[0],
+                                      idx.ctypes.data, m, x.ctypes.data, fun.ctypes.data, nit.ctypes.data,
+                                      st.ctypes.data, int(trace_cap), tr.ctypes.data, tl.ctypes.data, int(device)))
+    n_par = 2 if fit == "gaussian" else 3
+    infos = []
+    for r in range(m):
+        pts = tr[r, : tl[r]]
+        steps = np.r_[np.nan, np.linalg.norm(np.diff(pts[:, :n_par], axis=0), axis=1)] if len(pts) else []
+        infos.append([{"f_val": float(p[3]), "grad_norm": None, "step_size": float(s)} for p, s in zip(pts, steps)])
+    return x[:, :n_par], st == _abi.ST_CONVERGED, nit, fun, st, infos
+
+
+def fit_voxel(voxel, fit, fit_params, TEeffs, reshaped_t2w, prior, norm, want_trace=True, **kw):
     """run_t2mapping.py:120-312 for one voxel: ``(params, success, nit, final_error, iteration_info)``.
 
     Like the reference, a voxel whose no-prior bounds are infeasible raises ValueError, and
     ``fit_params['param_bounds']`` is rewritten in place when ``prior`` is False (:243-245).
-    ``iteration_info`` is always empty: per-iteration traces feed only the reference's plots.
+    ``iteration_info`` holds the objective value and step length of every iteration, as the
+    reference's callbacks record them.
     """
     if not prior:
         fit_params["param_bounds"][0] = (reshaped_t2w[voxel, 0], 10000)
         fit_params["param_bounds"][1] = (10, 2000)
         if fit_params["param_bounds"][0][0] > 10000:
             raise ValueError("LBFGSB - one of the lower bounds is greater than an upper bound.")
-    x, ok, nit, fun, st = fit_voxels([voxel], fit, fit_params, TEeffs, reshaped_t2w, prior, norm, **kw)
+    if want_trace:
+        x, ok, nit, fun, st, infos = fit_voxels_trace([voxel], fit, fit_params, TEeffs, reshaped_t2w, prior, norm, **kw)
+    else:
+        x, ok, nit, fun, st = fit_voxels([voxel], fit, fit_params, TEeffs, reshaped_t2w, prior, norm, **kw)
+        infos = [[]]
     if not ok[0]:
         print(f"FAIL : Optimization failed for voxel {voxel}: status {int(st[0])}")
         print("Objective function value at optimum:", fun[0])
         print("params", x[0])
-    return x[0], bool(ok[0]), int(nit[0]), float(fun[0]), []
+    return x[0], bool(ok[0]), int(nit[0]), float(fun[0]), infos[0]
 
 
 # --------------------------------------------------------------------------------------------

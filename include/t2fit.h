@@ -143,6 +143,15 @@ int t2fit_voxels_host(const t2fit_config *cfg, const float *echoes, int layout, 
                       const int64_t *idx, int64_t n_idx, double *x, double *fun, int32_t *nit,
                       uint8_t *status, int device);
 
+/* The same with per-iteration traces -- what the reference's callbacks collect into
+ * iteration_info (run_t2mapping.py:180-234) and its convergence plots consume:
+ *   trace[n_idx * trace_cap * 4] float64: (k, T2, sigma, objective) after each iteration,
+ *   trace_len[n_idx]: iterations recorded (<= trace_cap; later ones are dropped). */
+int t2fit_voxels_trace_host(const t2fit_config *cfg, const float *echoes, int layout, int64_t n_vox,
+                            const int64_t *idx, int64_t n_idx, double *x, double *fun, int32_t *nit,
+                            uint8_t *status, int trace_cap, double *trace, int32_t *trace_len,
+                            int device);
+
 /* Union mask + flat indices: replaces run_t2mapping.py:383-384,412,421.
  *   masks_dev : n_masks volumes of uint8 [n_vox] each, contiguous (n_masks, n_vox)
  *   mask_out  : uint8 [n_vox], 1 where any input mask is non-zero

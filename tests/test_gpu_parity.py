@@ -506,3 +506,36 @@ def test_sharded_path_with_rccl_single_rank(t2):
             assert np.array_equal(getattr(got, name).cpu().numpy(), getattr(want, name), equal_nan=True), name
     finally:
         dist.destroy_process_group()
+
+
+def test_iteration_traces_match_reference_callbacks(t2):
+    """fit_voxel's iteration_info (objective value and step length per iteration, what the reference's
+    callbacks record at run_t2mapping.py:180-234) against the traces stored in the fixtures."""
+    for name in ("lf_gaussian_prior_te8", "hf_gaussian_rician_prior_te6", "lf_rician_noprior_te3"):
+        d = np.load(os.path.join(GOLDEN, f"voxels_{name}.npz"))
+        first = int(d["trace_first_row"])
+        rows = np.arange(first, first + d["trace_f"].shape[0])
+        x, ok, nit, fun, st, infos = t2.fit_voxels_trace(rows, str(d["mode"]), _table(t2, d), d["te"], d["y"],
+                                                         bool(d["prior"]), False, trace_cap=64)
+        dev_f, dev_s = [], []
+        for j, info in enumerate(infos):
+            assert len(info) == min(int(nit[j]), 64)
+            want_f = d["trace_f"][j][np.isfinite(d["trace_f"][j])]
+            want_s = d["trace_step"][j][: len(want_f)]
+            assert np.isnan(info[0]["step_size"]) and info[0]["grad_norm"] is None
+            n = min(3, len(info), len(want_f))  # the first iterations, before rounding noise is amplified
+            got_f = np.array([e["f_val"] for e in info[:n]])
+            dev_f.append(np.max(np.abs(got_f - want_f[:n]) / np.abs(want_f[:n])))
+            if n > 1:
+                got_s = np.array([e["step_size"] for e in info[1:n]])
+                dev_s.append(np.max(np.abs(got_s - want_s[1:n]) / np.abs(want_s[1:n])))
+            if len(info) == int(nit[j]):
+                assert np.isclose(info[-1]["f_val"], fun[j], rtol=1e-12)
+        # forward-difference noise makes individual iterates drift (host simulator over all 288 traced
+        # voxels: f p90 1.5e-5, max 0.09; steps p90 2.3e-4, max 0.15), so the bars are percentiles
+        assert np.median(dev_f) <= 1e-4 and np.mean(np.array(dev_f) <= 1e-2) >= 0.75 and max(dev_f) <= 0.3, (name, dev_f)
+        assert np.median(dev_s) <= 1e-2 and max(dev_s) <= 0.5, (name, dev_s)
+    # the one-voxel mirror returns the same 5-tuple shape as the reference
+    d = np.load(os.path.join(GOLDEN, "voxels_lf_gaussian_prior_te8.npz"))
+    p, success, n_it, ferr, info = t2.fit_voxel(20, "gaussian", _table(t2, d), d["te"], d["y"], True, False)
+    assert len(p) == 2 and isinstance(success, bool) and n_it == len(info) and set(info[0]) == {"f_val", "grad_norm", "step_size"}
