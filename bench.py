@@ -249,7 +249,7 @@ def main():
             traffic = t.get(key)
         masked = int(mask.sum().item())
         out = {
-            "metric": "Mvoxel/s T2 fit, 256^3 x 8TE 3-param, whole job",
+            "metric": "Mvoxel/s T2 fit, 256\u00b3\u00d78TE 3-param, 1/2/4/8 GPU; % HBM roofline",
             "value": round(value, 3), "unit": "Mvoxel/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if a.solver == "lbfgsb" else a.precision, "data": "synthetic",
