@@ -5,9 +5,11 @@
 // (ftol = gtol = 1e-2 for the 3-parameter model), so this solver is the "converged" alternative
 // to the trajectory-faithful L-BFGS-B lane solver in t2fit_lbfgsb.h, not a replica of it.
 //
-// Method: closed-form weighted log-linear seed, then projected LM in (k, R = 1/T2, sigma) with
-// Marquardt scaling, an active set taken from the gradient sign at the bounds, trial points
-// clipped to the box, and Nielsen's gain-ratio damping update.  T is float or double.
+// Method: closed-form weighted log-linear seed for (k, T2) and a data-driven seed for the noise
+// floor, then projected LM in (k, R = 1/T2) for the 2-parameter model and (k^2, R, sigma^2) for the
+// 3-parameter model, with Marquardt scaling, an active set taken from the gradient sign at the
+// bounds, trial points clipped to the box, Nielsen's gain-ratio damping update, and one restart from
+// the table start point when the seeded run ends with T2 on a bound.  T is float or double.
 #pragma once
 
 #include "t2fit_lane.h"

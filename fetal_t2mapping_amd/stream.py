@@ -8,6 +8,7 @@ Results are identical to calling ``fit_volume`` per subject (voxels are independ
 from __future__ import annotations
 
 import ctypes as C
+from concurrent.futures import ThreadPoolExecutor
 from typing import Iterable, Iterator, Optional, Tuple
 
 import numpy as np
@@ -15,6 +16,25 @@ import numpy as np
 from . import _abi
 from ._lib import check, require_gpu
 from .t2map import T2Maps, make_config
+
+
+_COPY_THREADS = 8
+_pool = None
+
+
+def _parallel_copy(dst: np.ndarray, src: np.ndarray) -> None:
+    """dst[:] = src for large flat float32 arrays, split over a few threads: a single-threaded
+    memcpy into the pinned staging buffer (about 10 GB/s) would otherwise cost more than the PCIe
+    transfer and the fit together (numpy releases the GIL while copying)."""
+    global _pool
+    n = dst.size
+    if n < (1 << 22):
+        dst[:] = src
+        return
+    if _pool is None:
+        _pool = ThreadPoolExecutor(_COPY_THREADS)
+    step = -(-n // _COPY_THREADS)
+    list(_pool.map(lambda i: dst.__setitem__(slice(i, min(i + step, n)), src[i:min(i + step, n)]), range(0, n, step)))
 
 
 class _Slot:
@@ -38,8 +58,14 @@ class _Slot:
 
 
 def fit_subjects(subjects: Iterable[Tuple[np.ndarray, Optional[np.ndarray]]], TEeffs, fit, fit_params, prior=True,
-                 norm=False, *, solver="lbfgsb", precision="f64", device=0, depth=2) -> Iterator[T2Maps]:
-    """Yield the maps of each ``(echoes (nTE,Z,Y,X) float32, mask (Z,Y,X) or None)`` in order."""
+                 norm=False, *, solver="lbfgsb", precision="f64", device=0, depth=2, copy_out=True) -> Iterator[T2Maps]:
+    """Yield the maps of each ``(echoes (nTE,Z,Y,X) float32, mask (Z,Y,X) or None)`` in order.
+
+    ``echoes`` may be a numpy array (copied into a pinned staging buffer by a few threads) or an
+    already pinned, contiguous float32 CPU torch tensor (DMA'd from where it lies: the decode stage
+    can write straight into pinned memory).  ``copy_out=False`` yields views of the pinned output
+    buffer instead of copies; they stay valid until ``depth`` further subjects have been yielded.
+    """
     import torch
 
     lib = require_gpu()
@@ -53,7 +79,11 @@ def fit_subjects(subjects: Iterable[Tuple[np.ndarray, Optional[np.ndarray]]], TE
         def finish(slot):
             slot.ev_d2h.synchronize()
             shape, n = slot.meta
-            out = slot.h_out[: 4 * n].numpy().reshape(4, n).copy()
+            if copy_out:
+                out = np.empty((4, n), np.float32)
+                _parallel_copy(out.reshape(-1), slot.h_out[: 4 * n].numpy())
+            else:
+                out = slot.h_out[: 4 * n].numpy().reshape(4, n)
             slot.meta = None
             return T2Maps(*(out[j].reshape(shape) for j in range(4)))
 
@@ -69,10 +99,19 @@ def fit_subjects(subjects: Iterable[Tuple[np.ndarray, Optional[np.ndarray]]], TE
             shape = tuple(echoes.shape[1:])
             n = int(np.prod(shape))
             slot.ensure(n_te, n)
-            slot.h_in[: n_te * n].numpy()[:] = np.asarray(echoes, np.float32).reshape(-1)
-            slot.h_mask[:n].numpy()[:] = 1 if mask is None else (np.asarray(mask).reshape(-1) != 0)
+            direct = (isinstance(echoes, torch.Tensor) and echoes.dtype == torch.float32 and echoes.is_contiguous()
+                      and not echoes.is_cuda and echoes.is_pinned())
+            src = echoes.reshape(-1) if direct else slot.h_in[: n_te * n]
+            if not direct:
+                _parallel_copy(slot.h_in[: n_te * n].numpy(), np.ascontiguousarray(echoes, np.float32).reshape(-1))
+            if mask is None:
+                slot.h_mask[:n].numpy()[:] = 1
+            else:
+                mk = np.asarray(mask).reshape(-1)
+                # the kernels test mask != 0 themselves: one-byte masks are staged as they are
+                _parallel_copy(slot.h_mask[:n].numpy(), mk.view(np.uint8) if mk.dtype.itemsize == 1 else (mk != 0).view(np.uint8))
             with torch.cuda.stream(s_in):
-                slot.d_in[: n_te * n].copy_(slot.h_in[: n_te * n], non_blocking=True)
+                slot.d_in[: n_te * n].copy_(src, non_blocking=True)
                 slot.d_mask[:n].copy_(slot.h_mask[:n], non_blocking=True)
                 slot.ev_h2d.record(s_in)
             compute.wait_event(slot.ev_h2d)
