@@ -11,8 +11,8 @@ OK, E_INVALID, E_HIP, E_BOUNDS = 0, -1, -2, -3
 MODEL_GAUSSIAN, MODEL_GAUSSIAN_RICIAN, MODEL_RICIAN = 0, 1, 2
 MODELS = {"gaussian": MODEL_GAUSSIAN, "gaussian_rician": MODEL_GAUSSIAN_RICIAN, "rician": MODEL_RICIAN}
 
-SOLVER_LBFGSB, SOLVER_LM = 0, 1
-SOLVERS = {"lbfgsb": SOLVER_LBFGSB, "L-BFGS-B": SOLVER_LBFGSB, "lm": SOLVER_LM}
+SOLVER_LBFGSB, SOLVER_LM, SOLVER_LOGLIN = 0, 1, 2
+SOLVERS = {"lbfgsb": SOLVER_LBFGSB, "L-BFGS-B": SOLVER_LBFGSB, "lm": SOLVER_LM, "loglin": SOLVER_LOGLIN}
 
 PREC_F64, PREC_F32 = 0, 1
 PRECISIONS = {"f64": PREC_F64, "f32": PREC_F32}

@@ -1,7 +1,7 @@
 """CLI and volume driver: the reference's ``run_t2mapping.py`` surface on the MI355X fit.
 
     python -m fetal_t2mapping_amd.cli --path /data/qMRI --csv 2024083017_17510000.csv \
-        --in_vivo --gaussian --lf --sim 1 [--TEs 114 202 299] [--no_prior] [--solver lbfgsb|lm]
+        --in_vivo --gaussian --lf --sim 1 [--TEs 114 202 299] [--no_prior] [--solver lbfgsb|lm|loglin]
 
 Same flags, metadata CSVs, input/output file names and maps as the reference
 (run_t2mapping.py:483-576, utils/metadata_utils.py, utils/qmri_utils.py:13-33,
@@ -208,8 +208,9 @@ def parse_arguments(argv=None):
     p.add_argument("--TEs", nargs="+", type=int, help="echo times [ms] to fit (default 114/115, 202, 299)")
     p.add_argument("--no_prior", action="store_true", help="k >= S(TE0) instead of the table's lower bound")
     p.add_argument("--norm", action="store_true", help="divide each voxel's samples by their maximum")
-    p.add_argument("--solver", choices=["lbfgsb", "lm"], default="lbfgsb",
-                   help="lbfgsb: the reference's solver and stop rules (default); lm: converged bounded LM")
+    p.add_argument("--solver", choices=["lbfgsb", "lm", "loglin"], default="lbfgsb",
+                   help="lbfgsb: the reference's solver and stop rules (default); lm: converged bounded LM; "
+                        "loglin: closed-form weighted log-linear fit (--gaussian only)")
     p.add_argument("--precision", choices=["f64", "f32"], default="f64", help="arithmetic of the lm solver")
     p.add_argument("--device", type=int, default=0, help="HIP device ordinal")
     return p.parse_args(argv)

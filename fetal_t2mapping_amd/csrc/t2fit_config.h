@@ -63,7 +63,14 @@ inline int config_check(const t2fit_config* c, const char** why) {
   if (!c) { *why = "cfg is NULL"; return T2FIT_E_INVALID; }
   if (c->abi_version != T2FIT_ABI_VERSION) { *why = "cfg.abi_version mismatch"; return T2FIT_E_INVALID; }
   if (c->model < 0 || c->model > 2) { *why = "unknown model"; return T2FIT_E_INVALID; }
-  if (c->solver != T2FIT_SOLVER_LBFGSB && c->solver != T2FIT_SOLVER_LM) { *why = "unknown solver"; return T2FIT_E_INVALID; }
+  if (c->solver != T2FIT_SOLVER_LBFGSB && c->solver != T2FIT_SOLVER_LM && c->solver != T2FIT_SOLVER_LOGLIN) {
+    *why = "unknown solver";
+    return T2FIT_E_INVALID;
+  }
+  if (c->solver == T2FIT_SOLVER_LOGLIN && c->model != T2FIT_MODEL_GAUSSIAN) {
+    *why = "the log-linear closed form exists for the 2-parameter gaussian model only";
+    return T2FIT_E_INVALID;
+  }
   if (c->solver == T2FIT_SOLVER_LM && c->model == T2FIT_MODEL_RICIAN) {
     *why = "the LM solver handles the least-squares models only; use T2FIT_SOLVER_LBFGSB for rician";
     return T2FIT_E_INVALID;

@@ -8,6 +8,7 @@
 #include "t2fit_lane.h"
 #include "t2fit_lbfgsb.h"
 #include "t2fit_lm.h"
+#include "t2fit_loglin.h"
 
 namespace t2fit {
 
@@ -80,7 +81,10 @@ T2_HD void fit_lane_t(const LaneParams& P, const ObjCtx& c, bool finite, float y
     r.status = T2FIT_ST_NONFINITE;
     return;
   }
-  if constexpr (SOLVER == T2FIT_SOLVER_LM) {
+  if constexpr (SOLVER == T2FIT_SOLVER_LOGLIN) {
+    static_assert(MODEL == T2FIT_MODEL_GAUSSIAN, "the log-linear closed form exists for the 2-parameter model only");
+    loglin_solve(c, lb, ub, true, r);
+  } else if constexpr (SOLVER == T2FIT_SOLVER_LM) {
     static_assert(MODEL != T2FIT_MODEL_RICIAN, "LM handles the least-squares models only");
     if constexpr (PREC == T2FIT_PREC_F32) lm_solve<float, NP>(c, lb, ub, r);
     else lm_solve<double, NP>(c, lb, ub, r);

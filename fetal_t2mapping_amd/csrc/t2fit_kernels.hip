@@ -147,6 +147,94 @@ __global__ __launch_bounds__(kBlock) void fit_volume_kernel(const LaneParams P, 
   store_result(m, v, o, r);
 }
 
+// Closed-form log-linear fit (T2FIT_SOLVER_LOGLIN), TE-major stacks: one streaming pass, four
+// consecutive voxels per lane so that every echo plane is read with 16-byte loads and every map is
+// written with 16-byte stores (1 KiB per wave instruction).  Fit, bounds, float32 casts, residual map
+// and the optional extras all happen in this pass: algorithmic HBM bytes = 4*nTE + 1 + 16 per voxel,
+// and nothing but HBM bounds it.  A lane whose four voxels are all outside the mask issues no echo
+// loads.  Samples are parked in LDS as [nTE][4][256] (lane-contiguous: conflict-free) so that the lane
+// math shared with the other solvers can address them by a run-time echo index.
+constexpr int kLoglinVec = 4;
+constexpr int kLoglinTile = kBlock * kLoglinVec;
+
+__global__ __launch_bounds__(kBlock) void loglin_volume_kernel(const LaneParams P, const float* __restrict__ echoes,
+                                                               const uint8_t* __restrict__ mask, int64_t n_vox,
+                                                               DevMaps m) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x;
+  const int64_t v0 = (int64_t)blockIdx.x * kLoglinTile + (int64_t)lane * kLoglinVec;
+  if (v0 >= n_vox) return;  // n_vox is a multiple of 4 on this path: a lane is all in or all out
+  const int n_te = P.n_te;
+  bool act[kLoglinVec] = {true, true, true, true};
+  if (mask) {
+    const uchar4 mk = *reinterpret_cast<const uchar4*>(mask + v0);
+    act[0] = mk.x != 0; act[1] = mk.y != 0; act[2] = mk.z != 0; act[3] = mk.w != 0;
+  }
+  const bool any = act[0] || act[1] || act[2] || act[3];
+  if (any) {
+    const float* src = echoes + v0;
+    for (int i0 = 0; i0 < n_te; i0 += 8) {  // up to eight 16-byte loads in flight per lane
+      float4 tmp[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (i0 + j < n_te) tmp[j] = *reinterpret_cast<const float4*>(src + (int64_t)(i0 + j) * n_vox);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (i0 + j < n_te) {
+          float* dst = lds + (i0 + j) * kLoglinTile + lane;
+          dst[0] = tmp[j].x; dst[kBlock] = tmp[j].y; dst[2 * kBlock] = tmp[j].z; dst[3 * kBlock] = tmp[j].w;
+        }
+    }
+  }
+  float o_t2[kLoglinVec], o_k[kLoglinVec], o_res[kLoglinVec];
+  const bool want_fun = m.fun != nullptr || m.fund != nullptr;
+#pragma unroll
+  for (int q = 0; q < kLoglinVec; ++q) {
+    o_t2[q] = 0.0f; o_k[q] = 0.0f; o_res[q] = 0.0f;
+    const int64_t v = v0 + q;
+    if (!act[q]) {
+      if (m.r2) m.r2[v] = 0.0f;
+      if (m.se) m.se[v] = 0.0f;
+      if (m.fun) m.fun[v] = 0.0f;
+      if (m.nit) m.nit[v] = 0;
+      if (m.status) m.status[v] = T2FIT_ST_MASKED;
+      if (m.xd) { m.xd[3 * v] = 0.0; m.xd[3 * v + 1] = 0.0; m.xd[3 * v + 2] = 0.0; }
+      if (m.fund) m.fund[v] = 0.0;
+      continue;
+    }
+    bool finite;
+    float y0_raw;
+    const ObjCtx c = prepare_samples(P, lds + q * kBlock + lane, kLoglinTile, finite, y0_raw);
+    double lb[3], ub[3];
+    const bool feasible = lane_bounds(P, y0_raw, lb, ub);
+    LaneResult r;
+    r.nit = 0; r.nfev = 0; r.fun = NAN;
+    if (!feasible) {
+      r.x[0] = NAN; r.x[1] = NAN; r.x[2] = 0.0;
+      r.status = T2FIT_ST_INFEASIBLE;
+    } else if (!finite) {
+      r.x[0] = t2_clip(P.x0[0], lb[0], ub[0]); r.x[1] = t2_clip(P.x0[1], lb[1], ub[1]); r.x[2] = 0.0;
+      r.status = T2FIT_ST_NONFINITE;
+    } else {
+      loglin_solve(c, lb, ub, want_fun, r);
+    }
+    LaneOutputs o;
+    lane_epilogue(c, r, o, m.r2 != nullptr, m.se != nullptr);
+    o_t2[q] = o.t2; o_k[q] = o.k; o_res[q] = o.res;
+    if (m.r2) m.r2[v] = o.r2;
+    if (m.se) m.se[v] = o.se;
+    if (m.fun) m.fun[v] = o.fun;
+    if (m.nit) m.nit[v] = o.nit;
+    if (m.status) m.status[v] = o.status;
+    if (m.xd) { m.xd[3 * v] = r.x[0]; m.xd[3 * v + 1] = r.x[1]; m.xd[3 * v + 2] = r.x[2]; }
+    if (m.fund) m.fund[v] = r.fun;
+  }
+  *reinterpret_cast<float4*>(m.t2 + v0) = make_float4(o_t2[0], o_t2[1], o_t2[2], o_t2[3]);
+  *reinterpret_cast<float4*>(m.k + v0) = make_float4(o_k[0], o_k[1], o_k[2], o_k[3]);
+  *reinterpret_cast<float4*>(m.sigma + v0) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  *reinterpret_cast<float4*>(m.res + v0) = make_float4(o_res[0], o_res[1], o_res[2], o_res[3]);
+}
+
 // Persistent form of the reference-trajectory fit.  The number of objective evaluations per voxel
 // varies 4..200 (line searches), so with one voxel per lane a wave waits for its slowest voxel
 // (measured lane efficiency 0.53).  Here a wave keeps all 64 lanes busy instead: waves pull chunks
@@ -482,6 +570,8 @@ FitKernel pick_kernel(const t2fit_config& c) {
                ? fit_volume_kernel<T2FIT_SOLVER_LM, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN>
                : fit_volume_kernel<T2FIT_SOLVER_LM, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN_RICIAN>;
   }
+  if (c.solver == T2FIT_SOLVER_LOGLIN)  // voxel-major stacks, ragged sizes, unaligned views: one voxel per lane
+    return fit_volume_kernel<T2FIT_SOLVER_LOGLIN, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN>;
   return nullptr;  // the L-BFGS-B solver runs in the persistent kernel
 }
 
@@ -514,6 +604,13 @@ int check_common(const t2fit_config* cfg, const void* echoes, int layout, int64_
   return T2FIT_OK;
 }
 
+// the 4-voxels-per-lane form needs 16-byte aligned planes and maps, a 4-byte aligned mask and <= 64 KiB of LDS
+bool loglin_vec_ok(const float* echoes, int layout, const uint8_t* mask, int64_t n_vox, const DevMaps& dm, int n_te) {
+  auto al = [](const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+  return layout == T2FIT_LAYOUT_TE_MAJOR && n_vox % kLoglinVec == 0 && al(echoes, 16) && al(mask, 4) && al(dm.t2, 16) &&
+         al(dm.k, 16) && al(dm.sigma, 16) && al(dm.res, 16) && (size_t)n_te * kLoglinTile * sizeof(float) <= 65536;
+}
+
 int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const uint8_t* mask, int64_t n_vox,
                const DevMaps& dm, hipStream_t st) {
   if (n_vox == 0) return T2FIT_OK;
@@ -528,7 +625,8 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
   const unsigned grid = (unsigned)((n_vox + kBlock - 1) / kBlock);
   const size_t lds = (size_t)cfg->n_te * kLdsStride * sizeof(float);
   FitKernel kern = pick_kernel(*cfg);
-  const bool persistent = g_use_persistent || cfg->solver == T2FIT_SOLVER_LBFGSB;
+  const bool loglin = cfg->solver == T2FIT_SOLVER_LOGLIN;
+  const bool persistent = !loglin && (g_use_persistent || cfg->solver == T2FIT_SOLVER_LBFGSB);
   if (persistent && n_vox >= 0xffffffffLL) return fail(T2FIT_E_INVALID, "n_vox must be below 2^32 per call");
   unsigned long long* counter = nullptr;
   if (persistent) {
@@ -568,6 +666,9 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
     }
     hipLaunchKernelGGL(residuals_kernel, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox,
                        (const float*)dm.t2, (const float*)dm.k, (const float*)dm.sigma, dm.res, dm.r2, dm.se);
+  } else if (loglin && loglin_vec_ok(echoes, layout, mask, n_vox, dm, cfg->n_te)) {
+    hipLaunchKernelGGL(loglin_volume_kernel, dim3((unsigned)((n_vox + kLoglinTile - 1) / kLoglinTile)), dim3(kBlock),
+                       (size_t)cfg->n_te * kLoglinTile * sizeof(float), st, P, echoes, mask, n_vox, dm);
   } else {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox, dm);
   }

@@ -43,18 +43,40 @@ class _Slot:
         self.cap_e = self.cap_n = 0
         self.meta = None
 
-    def ensure(self, n_te: int, n: int):
+    def ensure(self, n_te: int, n: int, need_h_in: bool):
         import torch
 
         if n_te * n > self.cap_e or n > self.cap_n:
             self.cap_e, self.cap_n = max(self.cap_e, n_te * n), max(self.cap_n, n)
-            self.h_in = torch.empty(self.cap_e, dtype=torch.float32).pin_memory()
+            self.h_in = None
             self.h_mask = torch.empty(self.cap_n, dtype=torch.uint8).pin_memory()
             self.h_out = torch.empty(4 * self.cap_n, dtype=torch.float32).pin_memory()
             self.d_in = torch.empty(self.cap_e, dtype=torch.float32, device=self.dev)
             self.d_mask = torch.empty(self.cap_n, dtype=torch.uint8, device=self.dev)
             self.d_out = torch.empty(4 * self.cap_n, dtype=torch.float32, device=self.dev)
             self.ev_h2d, self.ev_fit, self.ev_d2h = (torch.cuda.Event() for _ in range(3))
+        if need_h_in and self.h_in is None:  # only inputs that are not already pinned get staged
+            self.h_in = torch.empty(self.cap_e, dtype=torch.float32).pin_memory()
+
+
+# Page-locking a 256^3 x 8 TE staging set takes longer than fitting several subjects, so the
+# slots (pinned + device buffers, events) and the two copy streams outlive a fit_subjects() call.
+_contexts = {}
+
+
+def _context(dev, depth: int):
+    import torch
+
+    key = (dev.index, depth)
+    if key not in _contexts:
+        _contexts[key] = ([_Slot(dev) for _ in range(depth)], torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+    return _contexts[key]
+
+
+def release(device=None) -> None:
+    """Drop the cached staging buffers (all devices, or one)."""
+    for key in [k for k in _contexts if device is None or k[0] == device]:
+        del _contexts[key]
 
 
 def fit_subjects(subjects: Iterable[Tuple[np.ndarray, Optional[np.ndarray]]], TEeffs, fit, fit_params, prior=True,
@@ -73,8 +95,11 @@ def fit_subjects(subjects: Iterable[Tuple[np.ndarray, Optional[np.ndarray]]], TE
     dev = torch.device("cuda", device)
     with torch.cuda.device(dev):
         compute = torch.cuda.current_stream()
-        s_in, s_out = torch.cuda.Stream(), torch.cuda.Stream()
-        slots = [_Slot(dev) for _ in range(depth)]
+        slots, s_in, s_out = _context(dev, depth)
+        for slot in slots:  # an abandoned earlier generator may have left copies in flight
+            if slot.meta is not None:
+                slot.ev_d2h.synchronize()
+                slot.meta = None
 
         def finish(slot):
             slot.ev_d2h.synchronize()
@@ -98,9 +123,9 @@ def fit_subjects(subjects: Iterable[Tuple[np.ndarray, Optional[np.ndarray]]], TE
                 raise ValueError("every subject must have the configured number of echoes")
             shape = tuple(echoes.shape[1:])
             n = int(np.prod(shape))
-            slot.ensure(n_te, n)
             direct = (isinstance(echoes, torch.Tensor) and echoes.dtype == torch.float32 and echoes.is_contiguous()
                       and not echoes.is_cuda and echoes.is_pinned())
+            slot.ensure(n_te, n, not direct)
             src = echoes.reshape(-1) if direct else slot.h_in[: n_te * n]
             if not direct:
                 _parallel_copy(slot.h_in[: n_te * n].numpy(), np.ascontiguousarray(echoes, np.float32).reshape(-1))

@@ -105,6 +105,8 @@ def make_config(fit: str, fit_params: dict, TEeffs, prior: bool = True, norm: bo
     cfg.norm = int(bool(norm))
     cfg.solver = _abi.SOLVERS[solver]
     cfg.precision = _abi.PRECISIONS[precision]
+    if cfg.solver == _abi.SOLVER_LOGLIN and fit != "gaussian":
+        raise ValueError("solver 'loglin' is the closed form of the 2-parameter 'gaussian' fit only")
     if cfg.solver == _abi.SOLVER_LM:
         cfg.maxiter = 0  # library default for LM
     return cfg

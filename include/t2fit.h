@@ -47,6 +47,11 @@ extern "C" {
 #define T2FIT_SOLVER_LM 1     /* log-linear seed + bounded Levenberg-Marquardt run to convergence of
                                  the same objective and bounds (least-squares models only)          */
 
+#define T2FIT_SOLVER_LOGLIN 2 /* closed-form weighted log-linear regression ln y = ln k - t/T2 (weights
+                                 y^2), clipped into the same bounds; 2-parameter model only; one pass,
+                                 HBM-bound.  Extension named by BASELINE.json config 2: the reference
+                                 has no log-linear routine (parity with it is unpinned)               */
+
 /* arithmetic of the LM solver (the L-BFGS-B solver is always float64) */
 #define T2FIT_PREC_F64 0
 #define T2FIT_PREC_F32 1

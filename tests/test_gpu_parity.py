@@ -330,6 +330,15 @@ def test_streamed_subjects_equal_per_subject_fits(t2):
         for name in ("t2", "k", "sigma", "res"):
             assert np.array_equal(getattr(g, name), getattr(want, name), equal_nan=True)
     assert list(stream.fit_subjects([], te, "gaussian_rician", table)) == []
+    # second call reuses the cached staging slots; already pinned inputs are DMA'd from where they lie
+    import torch
+
+    pinned = [(torch.from_numpy(e).pin_memory(), m) for e, m in subs[:3]]
+    again = list(stream.fit_subjects(pinned, te, "gaussian_rician", table, solver="lm", precision="f32"))
+    for g, a in zip(got, again):
+        for name in ("t2", "k", "sigma", "res"):
+            assert np.array_equal(getattr(g, name), getattr(a, name), equal_nan=True)
+    stream.release()
 
 
 def test_options_against_live_oracle(t2):
