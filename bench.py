@@ -59,7 +59,7 @@ def parse():
     p.add_argument("--shape", type=int, nargs=3, default=[256, 256, 256], help="per-rank slab Z Y X")
     p.add_argument("--n-te", type=int, default=8)
     p.add_argument("--fit", default="gaussian_rician", choices=["gaussian", "gaussian_rician", "rician"])
-    p.add_argument("--solver", default="lbfgsb", choices=["lbfgsb", "lm"])
+    p.add_argument("--solver", default="lbfgsb", choices=["lbfgsb", "lm", "loglin"])
     p.add_argument("--precision", default="f64", choices=["f64", "f32"])
     p.add_argument("--no-prior", action="store_true")
     p.add_argument("--no-gather", action="store_true", help="skip the all-gather of the maps (N > 1)")
@@ -210,13 +210,12 @@ def main():
 
     # secondary measurement, same data: the converged bounded-LM solver in float32 (north_star's
     # "per-lane Levenberg-Marquardt"); reported beside the headline, never as `value`
-    also = None
-    if a.solver == "lbfgsb" and a.fit != "rician" and not a.no_also:
-        cfg2 = t2.make_config(a.fit, table, te, prior=not a.no_prior, norm=False, solver="lm", precision="f32")
+    def measure(cfg_x):
+        """Mean kernel time (HIP events on the launch stream) and mean wall time per launch of one more solver."""
         n2 = max(3, min(10, a.steps))
         ks = []
         for i in range(n2 + 1):
-            check(lib.t2fit_volume_dev(C.byref(cfg2), echoes.data_ptr(), _abi.LAYOUT_TE_MAJOR, mask.data_ptr(), n_vox,
+            check(lib.t2fit_volume_dev(C.byref(cfg_x), echoes.data_ptr(), _abi.LAYOUT_TE_MAJOR, mask.data_ptr(), n_vox,
                                        C.byref(maps), st))
             k = lib.t2fit_last_kernel_ms()
             if i:
@@ -224,16 +223,29 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(n2):
-            check(lib.t2fit_volume_dev(C.byref(cfg2), echoes.data_ptr(), _abi.LAYOUT_TE_MAJOR, mask.data_ptr(), n_vox,
+            check(lib.t2fit_volume_dev(C.byref(cfg_x), echoes.data_ptr(), _abi.LAYOUT_TE_MAJOR, mask.data_ptr(), n_vox,
                                        C.byref(maps), st))
         torch.cuda.synchronize()
         dt2 = (time.perf_counter() - t1) / n2
         kk = float(np.mean(ks))
-        also = {"solver": "lm", "dtype": "f32", "per_gpu_value": round(n_vox / dt2 / 1e6, 3), "unit": "Mvoxel/s",
-                "ms_per_step": round(dt2 * 1e3, 4), "kernel_ms": round(kk, 4),
-                "roofline_frac": round((4 * a.n_te + 17) * n_vox / (kk * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+        return {"per_gpu_value": round(n_vox / dt2 / 1e6, 3), "unit": "Mvoxel/s", "ms_per_step": round(dt2 * 1e3, 4),
+                "kernel_ms": round(kk, 4),
+                "roofline_frac": round((4 * a.n_te + 17) * n_vox / (kk * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
+
+    also = also_loglin = None
+    if a.solver == "lbfgsb" and a.fit != "rician" and not a.no_also:
+        cfg2 = t2.make_config(a.fit, table, te, prior=not a.no_prior, norm=False, solver="lm", precision="f32")
+        also = {"solver": "lm", "dtype": "f32", **measure(cfg2),
                 "note": "converged bounded LM of the same objective; differs from the reference's early-stopped "
                         "result by design (DESIGN.md section 2), no all-gather in this figure"}
+        # the one fit on the path that IS bound by HBM: closed-form log-linear 2-parameter fit of the same stack
+        # (BASELINE.json config 2 names it; the reference has no such routine), fit + residual map in one pass
+        cfg3 = t2.make_config("gaussian", t2.fit_table("gaussian", True), te, prior=not a.no_prior, norm=False,
+                              solver="loglin")
+        also_loglin = {"solver": "loglin", "fit": "gaussian", "dtype": "f64 sums over f32 log", **measure(cfg3),
+                       "kernel": "loglin_volume_kernel",
+                       "note": "closed-form weighted log-linear 2-parameter fit, one streaming pass (fit + residual map); "
+                               "an extension, not the reference's solver: never `value`"}
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         value = world * n_vox / (elapsed / a.steps) / 1e6
@@ -254,22 +266,26 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if a.solver == "lbfgsb" else a.precision, "data": "synthetic",
             "config": {"workload": f"{z}x{y}x{x} voxels x {a.n_te} TE per GPU, {a.fit} objective, "
-                                   f"{'reference-trajectory L-BFGS-B' if a.solver == 'lbfgsb' else 'bounded LM'} solver, "
+                                   f"{ {'lbfgsb': 'reference-trajectory L-BFGS-B', 'lm': 'bounded LM', 'loglin': 'closed-form log-linear'}[a.solver]} solver, "
                                    f"{'prior' if not a.no_prior else 'no-prior'} bounds, mask fill {masked / n_vox:.2f}",
                        "solver": a.solver, "fit": a.fit, "n_te": a.n_te, "voxels_per_gpu": n_vox,
                        "masked_voxels_per_gpu": masked,
                        "parallelism": f"voxel slabs x{world}" + (" + all-gather of 4 maps (overlapped with the next fit)" if do_gather else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": "fit_persistent_kernel", "kernel_ms": round(k_ms, 4),
+                         "kernel": "loglin_volume_kernel" if a.solver == "loglin" else "fit_persistent_kernel",
+                         "kernel_ms": round(k_ms, 4),
                          "bytes_per_voxel": bytes_per_voxel,
-                         "note": "the fit is float64 VALU bound (exp/sqrt/div per objective evaluation), not HBM "
-                                 "bound: see DESIGN.md section 6"},
+                         "note": ("one streaming pass, HBM bound" if a.solver == "loglin" else
+                                  "the fit is float64 VALU bound (exp/sqrt/div per objective evaluation), not HBM "
+                                  "bound: see DESIGN.md section 6")},
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if also is not None:
             out["also"] = also
+        if also_loglin is not None:
+            out["also_loglin"] = also_loglin
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -6,9 +6,10 @@
 Same flags, metadata CSVs, input/output file names and maps as the reference
 (run_t2mapping.py:483-576, utils/metadata_utils.py, utils/qmri_utils.py:13-33,
 utils/t2map_utils.py:18-59); the voxel loop (:411-461) is one call into the HIP library.  NIfTI I/O
-stays SimpleITK on the host, as in the reference.  Not carried over: the matplotlib convergence plots
-(:465-468, they need per-iteration Python lists for 50 random voxels) and the hard-coded ``prj-00X``
-CSV lists of the authors' lab (utils/metadata_utils.py:19-85) -- pass the CSV names instead.
+stays SimpleITK on the host, as in the reference (nifti.py stands in where SimpleITK is not installed).
+The convergence-study figures (:465-468) are written on request (--plots, convergence.py).  Not carried
+over: the hard-coded ``prj-00X`` CSV lists of the authors' lab (utils/metadata_utils.py:19-85) -- pass
+the CSV names instead.
 """
 from __future__ import annotations
 
@@ -29,11 +30,38 @@ t2map_dirname = recon_dirname + "_t2map"
 
 
 def _sitk():
+    """NIfTI I/O: SimpleITK as in the reference when it is importable, else the package's own NIfTI-1
+    reader/writer (same five calls, same (Z,Y,X) arrays and LPS geometry; fetal_t2mapping_amd/nifti.py)."""
     try:
         import SimpleITK as sitk
-    except ImportError as e:  # the fit does not need it; only the file edge does
-        raise RuntimeError("SimpleITK is required for NIfTI I/O (pip install SimpleITK)") from e
+    except ImportError:
+        from . import nifti as sitk
     return sitk
+
+
+def _read_subject(sitk, recon_paths, mask_paths, label_path):
+    """All volumes of one (sub, ses): echoes, masks, optional vial labels, and the last recon image (its
+    geometry goes onto the maps, run_t2mapping.py:377 / utils/t2map_utils.py:22-24).  With the native
+    reader the files are decoded concurrently, the echoes straight into one float32 (nTE,Z,Y,X) block."""
+    from . import nifti
+
+    if sitk is nifti:
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(8) as pool:
+            masks_f = pool.map(nifti.ReadImage, mask_paths)
+            label_f = pool.submit(nifti.ReadImage, label_path) if label_path else None
+            stack, images = nifti.read_stack(recon_paths)
+            masks = [m.arr for m in masks_f]
+            label = label_f.result().arr if label_f else None
+        return list(stack), masks, label, images[-1]
+    vols, masks, recon_img = [], [], None
+    for rp, mp in zip(recon_paths, mask_paths):
+        recon_img = sitk.ReadImage(rp)
+        masks.append(sitk.GetArrayFromImage(sitk.ReadImage(mp)))
+        vols.append(sitk.GetArrayFromImage(recon_img))
+    label = sitk.GetArrayFromImage(sitk.ReadImage(label_path)) if label_path else None
+    return vols, masks, label, recon_img
 
 
 # ---- metadata / paths --------------------------------------------------------------------------
@@ -133,39 +161,38 @@ def _fit_subject(vols, masks, keep, te_eff, fit, fit_params, prior, norm, solver
                             norm=norm, solver=solver, precision=precision, extras=True)
     torch.cuda.synchronize()
     out = tuple(getattr(maps, n).cpu().numpy() for n in ("t2", "k", "sigma", "res"))
-    return mask, out, maps.status.cpu().numpy()
+    extras = {"nit": maps.nit.cpu().numpy(), "fun": maps.fun.cpu().numpy()}  # what the convergence figures need
+    return mask, out, maps.status.cpu().numpy(), extras
 
 
 def process_t2maps(metadata, bids_path, TEs, fit, fit_params, phantom, low_field, prior, fast, norm, sim,
-                   solver="lbfgsb", precision="f64", device=0):
-    """run_t2mapping.py:333-479 with the voxel loop on the GPU."""
+                   solver="lbfgsb", precision="f64", device=0, plots=False, plot_seed=None):
+    """run_t2mapping.py:333-479 with the voxel loop on the GPU.  ``plots``: also write the reference's
+    convergence-study figures (:465-468) under <prj>/ada/convergence_analysis."""
     sitk = _sitk()
     tes_s = [x / 1000 for x in TEs]
     metadata = metadata[metadata["EchoTime"].isin(tes_s)]
     for prj, prj_md in metadata.groupby("prj"):
         for (sub, ses), sub_md in prj_md.groupby(["sub", "ses"]):
-            vols, masks, te_eff = [], [], []
+            recon_paths, mask_paths, te_eff, label_path = [], [], [], None
             for echotime, acq in sub_md.groupby("EchoTime"):
                 te_eff.append(echotime * 1000)
-                recon_path = get_img_path(bids_path, acq.iloc[0], recon_dirname).replace(" ", "")
-                mask_path = get_img_path(bids_path, acq.iloc[0], mask_dirname).replace(" ", "")
+                recon_paths.append(get_img_path(bids_path, acq.iloc[0], recon_dirname).replace(" ", ""))
+                mask_paths.append(get_img_path(bids_path, acq.iloc[0], mask_dirname).replace(" ", ""))
                 if phantom:
                     label_path = get_img_path(bids_path, acq.iloc[0], phantom_labels_dirname).replace(" ", "")
-                recon_img = sitk.ReadImage(recon_path)
-                masks.append(sitk.GetArrayFromImage(sitk.ReadImage(mask_path)))
-                vols.append(sitk.GetArrayFromImage(recon_img))
-            label = sitk.GetArrayFromImage(sitk.ReadImage(label_path)) if phantom else None
             te_eff = np.array(te_eff)
             if not np.array_equal(te_eff, TEs):
                 print(f"Warning: one or more TEs selected to fit is missing for {sub}_{ses}. T2 fit is skipped.")
                 continue
+            vols, masks, label, recon_img = _read_subject(sitk, recon_paths, mask_paths, label_path)
             keep = (label != 0) if (phantom and fast) else None  # :394-400
             print(f"T2 Mapping: {prj}_{sub}_{ses}")
             print(f"TEeffs: {te_eff}")
             print(f"Fitting using {fit} model ... ")
             t0 = time.time()
-            mask, (t2_map, k_map, sigma_map, res_map), status = _fit_subject(
-                vols, masks, keep, te_eff, fit, fit_params, prior, norm, solver, precision, device)
+            fitted = _fit_subject(vols, masks, keep, te_eff, fit, fit_params, prior, norm, solver, precision, device)
+            mask, (t2_map, k_map, sigma_map, res_map), status = fitted[:3]
             print(f"Dimensions of the t2w images: {mask.shape + (te_eff.size,)} (z,y,x,necho)")
             print(f"Mask Dimension: {mask.shape} -  Number of voxels inside mask: {int(np.sum(mask))}")
             if np.any(status == 4):  # scipy raises here and the reference's pool.map aborts the run
@@ -174,6 +201,13 @@ def process_t2maps(metadata, bids_path, TEs, fit, fit_params, phantom, low_field
             if n_fail:
                 print(f"FAIL : Optimization failed for {n_fail} voxels")
             print(f"... done. Time to fit: {round(time.time() - t0, 4)} sec")
+            if plots and len(fitted) > 3 and solver != "loglin":  # the closed form has no iterations to plot
+                from . import convergence
+
+                convergence.convergence_study(convergence.set_ada_path(bids_path, prj), vols,
+                                              np.flatnonzero(mask.reshape(-1)), t2_map, fitted[3]["nit"], fitted[3]["fun"],
+                                              te_eff, fit, fit_params, prior, norm, sub, ses, sim, solver=solver,
+                                              precision=precision, device=device, seed=plot_seed)
             save_nifti_maps(t2_map, k_map, sigma_map, res_map, t2map_dirname, recon_img, bids_path, acq, sim, fit)
             if phantom:
                 # the reference unpacks (gt, id) as id, gt (run_t2mapping.py:27 vs :478), which swaps the
@@ -213,6 +247,10 @@ def parse_arguments(argv=None):
                         "loglin: closed-form weighted log-linear fit (--gaussian only)")
     p.add_argument("--precision", choices=["f64", "f32"], default="f64", help="arithmetic of the lm solver")
     p.add_argument("--device", type=int, default=0, help="HIP device ordinal")
+    p.add_argument("--plots", action="store_true",
+                   help="write the reference's convergence-study PNGs (run_t2mapping.py:465-468) under "
+                        "<prj>/ada/convergence_analysis; off by default, the reference always draws them")
+    p.add_argument("--plot_seed", type=int, default=None, help="seed of the voxel sample in the figures")
     return p.parse_args(argv)
 
 
@@ -233,7 +271,8 @@ def main(argv=None):
     fit, fit_params = t2map.set_fit_params(args)
     metadata = set_metadata(csv_path, args.csv, low_field)
     process_t2maps(metadata, bids_path, TEs, fit, fit_params, phantom, low_field, not args.no_prior, fast,
-                   bool(args.norm), args.sim, solver=args.solver, precision=args.precision, device=args.device)
+                   bool(args.norm), args.sim, solver=args.solver, precision=args.precision, device=args.device,
+                   plots=args.plots, plot_seed=args.plot_seed)
 
 
 if __name__ == "__main__":

@@ -177,27 +177,58 @@ T2_HD bool lane_bounds(const LaneParams& P, float y0_raw, double* lb, double* ub
   return ok;
 }
 
+// a / b from r = 1/b (correctly rounded) with one residual correction: the correctly rounded quotient
+// except for rare last-bit cases, at three FMA-class operations instead of an IEEE division sequence
+T2_HD double t2_div_by_rcp(double a, double b, double r) {
+  const double q = a * r;
+  return fma(fma(-q, b, a), r, q);
+}
+
 // Mean signed residual from the float32 maps (utils/t2map_utils.py:62-89): float64 prediction
 // stored as float32, float32 residuals, numpy's pairwise float32 row sum, divided by nTE.
 T2_HD float residual_mean(const ObjCtx& c, float k32, float t232, float s32) {
   const int n = c.P->n_te;
   const bool gauss = c.P->model == T2FIT_MODEL_GAUSSIAN;
+  const double k = (double)k32, t2 = (double)t232;
+  const double k2 = (double)(k32 * k32), s2 = (double)(s32 * s32);  // float32 squares, as numpy
+  const double rt2 = 1.0 / t2;
+  auto resid = [&](int i) {
+    const double te = c.P->te[i];
+    double pred;
+    if (gauss) pred = k * t2_exp(t2_div_by_rcp(-te, t2, rt2));
+    else pred = t2_sqrt(k2 * t2_exp(t2_div_by_rcp(-2.0 * te, t2, rt2)) + s2);
+    return c.sample(i) - (float)pred;
+  };
   // numpy float32 add.reduce over a contiguous row: n < 8 sequential from 0; otherwise eight
   // interleaved partial sums over the first n - n%8 items, combined as a balanced tree, then the
-  // remaining items added one by one.  r8 is indexed through selects so it stays in registers.
+  // remaining items added one by one.
+  if (n <= 8) {  // the usual echo-train lengths: straight-line code, the eight exp() chains interleave
+    float r[8];
+#if defined(T2_DEVICE_COMPILE)
+#pragma unroll
+#endif
+    for (int i = 0; i < 8; ++i) r[i] = i < n ? resid(i) : 0.0f;
+    float sum;
+    if (n == 8) {
+      sum = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    } else {
+      sum = 0.0f;
+#if defined(T2_DEVICE_COMPILE)
+#pragma unroll
+#endif
+      for (int i = 0; i < 7; ++i)
+        if (i < n) sum += r[i];
+    }
+    return sum / (float)n;
+  }
+  // longer trains: r8 is indexed through selects so it stays in registers
   float r8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float sum = 0.0f;
   const int n8 = n & ~7;
-  const double k = (double)k32, t2 = (double)t232;
-  const double k2 = (double)(k32 * k32), s2 = (double)(s32 * s32);  // float32 squares, as numpy
   for (int i = 0; i < n; ++i) {
-    double pred;
-    if (gauss) pred = k * t2_exp(-c.P->te[i] / t2);
-    else pred = t2_sqrt(k2 * t2_exp(-2.0 * c.P->te[i] / t2) + s2);
-    const float r = c.sample(i) - (float)pred;
-    if (n < 8 || i >= n8) {
-      if (n >= 8 && i == n8)
-        sum = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+    const float r = resid(i);
+    if (i >= n8) {
+      if (i == n8) sum = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
       sum += r;
     } else {
       const int slot = i & 7;
@@ -207,7 +238,7 @@ T2_HD float residual_mean(const ObjCtx& c, float k32, float t232, float s32) {
       for (int j = 0; j < 8; ++j) r8[j] = (j == slot) ? r8[j] + r : r8[j];
     }
   }
-  if (n >= 8 && n8 == n) sum = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+  if (n8 == n) sum = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
   return sum / (float)n;
 }
 

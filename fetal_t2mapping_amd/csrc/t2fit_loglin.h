@@ -23,21 +23,35 @@ T2_HD float t2_logf_precise(float x) { return logf(x); }  // the ~1 ulp library 
 // weighted echo times are degenerate.
 T2_HD bool loglin_closed_form(const ObjCtx& c, double& k, double& t2) {
   const LaneParams& P = *c.P;
-  double sw = 0.0, st = 0.0, stt = 0.0, sl = 0.0, stl = 0.0;
-  int cnt = 0;
+  // One pass over the echoes, numerically equal to the centred two-pass form: t and ln y are taken
+  // relative to the heaviest sample (the pivot), which then contributes exactly zero to every sum.
+  // The textbook one-pass form (sw*stl - st*sl) / (sw*stt - st^2) cancels catastrophically when one
+  // sample carries nearly all the weight (a decay much faster than the echo spacing); with that
+  // sample as the pivot the subtracted terms are second order in the other samples' weights.
+  int piv = 0, cnt = 0;
+  float ypiv = c.sample(0);
+  for (int i = 0; i < P.n_te; ++i) {
+    const float yf = c.sample(i);
+    if (yf > ypiv) { ypiv = yf; piv = i; }
+    cnt += yf > 0.0f;
+  }
+  if (cnt < 2) return false;
+  const double tp = P.te[piv], lp = (double)t2_logf_precise(ypiv);
+  double sw = 0.0, st = 0.0, sl = 0.0, stt = 0.0, stl = 0.0;
   for (int i = 0; i < P.n_te; ++i) {
     const float yf = c.sample(i);
     if (yf > 0.0f) {
-      const double y = (double)yf, t = P.te[i];
-      const double w = y * y, l = (double)t2_logf_precise(yf);
-      sw += w; st += w * t; stt += w * t * t; sl += w * l; stl += w * t * l;
-      ++cnt;
+      const double y = (double)yf, w = y * y;
+      const double dt = P.te[i] - tp, dl = (double)t2_logf_precise(yf) - lp;
+      const double wt = w * dt;
+      sw += w; st += wt; sl += w * dl; stt += wt * dt; stl += wt * dl;
     }
   }
-  const double det = sw * stt - st * st;
-  if (cnt < 2 || !(det > 0.0)) return false;
-  const double slope = (sw * stl - st * sl) / det;  // = -1/T2
-  const double icpt = (sl - slope * st) / sw;       // = ln k
+  const double rsw = 1.0 / sw;
+  const double sxx = stt - st * st * rsw, sxy = stl - st * sl * rsw;
+  if (!(sxx > 0.0)) return false;
+  const double slope = sxy / sxx;                                   // = -1/T2
+  const double icpt = (lp + sl * rsw) - slope * (tp + st * rsw);    // = ln k
   if (!t2_finite(slope) || !t2_finite(icpt)) return false;
   // a flat or rising signal has no finite decay time: +inf, which the box clips to its upper end
   t2 = slope < 0.0 ? -1.0 / slope : (double)INFINITY;

@@ -13,6 +13,7 @@ What is restated, and where it lives in the reference (paths relative to /root/r
 * per-voxel bounded fit ............. run_t2mapping.py:237-312      -> ``fit_voxel``
 * result scatter to maps ............ run_t2mapping.py:415-418,449-458 -> ``fit_volume``
 * mean signed residual map .......... utils/t2map_utils.py:62-89   -> ``compute_residuals``
+* (extension, no reference code) closed-form log-linear 2-parameter fit -> ``loglinear_fit``
 
 Third-party arithmetic on the path that is NOT under /root/reference: ``scipy.optimize.minimize
 (method="L-BFGS-B")`` (Byrd, Lu, Nocedal, Zhu 1995; Zhu et al. 1997 L-BFGS-B 3.0 with the
@@ -212,6 +213,45 @@ def voxel_bounds(fit_params, y0, prior):
     lb = np.array([t[0] for t in b])
     ub = np.array([t[1] for t in b])
     return lb, ub
+
+
+# --- closed-form log-linear fit (no reference counterpart) -----------------------------------------
+def loglinear_fit(rows, TEeffs, fit_params, prior=True):
+    """Weighted log-linear regression ``ln y = ln k - t/T2`` with weights ``y**2`` over the positive
+    samples of each row, clipped into the voxel's bounds: the definition T2FIT_SOLVER_LOGLIN implements.
+
+    BASELINE.json configuration 2 names a "2-param log-linear fit"; the reference has none
+    (run_t2mapping.py:260-272 runs L-BFGS-B for the 2-parameter model too), so this is the oracle of
+    an extension, not a restatement: parity with the reference is unpinned for it.  float64 throughout.
+    Returns ``(x (M,2) [k, T2], ok (M,) bool)``; rows without two positive samples get the clipped
+    table start point and ``ok`` False.
+    """
+    rows = np.asarray(rows, np.float64)
+    te = np.asarray(TEeffs, np.float64)
+    x = np.zeros((rows.shape[0], 2))
+    ok = np.zeros(rows.shape[0], bool)
+    x0 = np.asarray(fit_params["initial_guess"], np.float64)[:2]
+    for v, y in enumerate(rows):
+        lb, ub = voxel_bounds(fit_params, np.float32(y[0]), prior)
+        pos = y > 0
+        w = np.where(pos, y * y, 0.0)
+        with np.errstate(all="ignore"):
+            l = np.where(pos, np.log(np.where(pos, y, 1.0)), 0.0)
+        sw = w.sum()
+        if pos.sum() < 2 or not sw > 0 or not np.all(np.isfinite(y)):
+            x[v] = np.clip(x0, lb[:2], ub[:2])
+            continue
+        tbar, lbar = (w * te).sum() / sw, (w * l).sum() / sw
+        sxx = (w * (te - tbar) ** 2).sum()
+        if not sxx > 0:
+            x[v] = np.clip(x0, lb[:2], ub[:2])
+            continue
+        slope = (w * (te - tbar) * (l - lbar)).sum() / sxx   # centred form: no cancellation
+        icpt = lbar - slope * tbar
+        t2 = -1.0 / slope if slope < 0 else np.inf
+        x[v] = np.clip([np.exp(min(icpt, 700.0)), t2], lb[:2], ub[:2])
+        ok[v] = True
+    return x, ok
 
 
 # --- tight-tolerance bounded minimiser of the same objective (no reference counterpart) --------

@@ -11,7 +11,9 @@ using namespace t2fit;
 
 // runtime switch over the lane-solver instantiations (the kernels pick theirs at launch time)
 static void fit_lane(const LaneParams& P, const ObjCtx& c, bool finite, float y0_raw, LaneResult& r) {
-  if (P.solver == T2FIT_SOLVER_LM) {
+  if (P.solver == T2FIT_SOLVER_LOGLIN) {
+    fit_lane_t<T2FIT_SOLVER_LOGLIN, T2FIT_PREC_F64, T2FIT_MODEL_GAUSSIAN>(P, c, finite, y0_raw, r);
+  } else if (P.solver == T2FIT_SOLVER_LM) {
     if (P.precision == T2FIT_PREC_F32) {
       if (P.model == T2FIT_MODEL_GAUSSIAN) fit_lane_t<T2FIT_SOLVER_LM, T2FIT_PREC_F32, T2FIT_MODEL_GAUSSIAN>(P, c, finite, y0_raw, r);
       else fit_lane_t<T2FIT_SOLVER_LM, T2FIT_PREC_F32, T2FIT_MODEL_GAUSSIAN_RICIAN>(P, c, finite, y0_raw, r);

@@ -87,3 +87,41 @@ def test_missing_te_is_skipped(tmp_path, monkeypatch, capsys):
     R.process_t2maps(md, bids, [114, 202, 250], "gaussian", O.fit_table("gaussian", True), False, True, True, False,
                      False, "s")
     assert "T2 fit is skipped" in capsys.readouterr().out and not sitk.written
+
+
+def test_convergence_figures_from_traces(tmp_path, monkeypatch):
+    """convergence.py (run_t2mapping.py:465-468): sampling, row gathering and the three file names, with
+    the trace entry point replaced by the oracle's own traces (the GPU test draws them from the device)."""
+    pytest.importorskip("matplotlib")
+    from fetal_t2mapping_amd import convergence, t2map
+
+    d = np.load(os.path.join(GOLDEN, "volume_lf_gaussian_noprior.npz"))
+    te, vols = d["te"], list(d["echoes"])
+    mask = d["masks"].sum(axis=0) > 0
+    idx = np.flatnonzero(mask.reshape(-1))
+    seen = {}
+
+    def fake_trace(indices, fit, fit_params, TEeffs, rows, prior, norm, **kw):
+        seen["rows"] = rows
+        infos = []
+        for r in indices:
+            infos.append(O.fit_voxel(int(r), fit, O.fit_table(fit, True), TEeffs, rows, prior, norm)[4])
+        return None, None, None, None, None, infos
+
+    monkeypatch.setattr(t2map, "fit_voxels_trace", fake_trace)
+    ada = convergence.set_ada_path(str(tmp_path), "prj-900")
+    n = mask.size
+    nit, fun = np.zeros(n, np.int32), np.zeros(n, np.float32)
+    nit[idx], fun[idx] = 5, 1.0
+    out = convergence.convergence_study(ada, vols, idx, d["t2"], nit, fun, te, "gaussian", O.fit_table("gaussian", True),
+                                        False, False, "sub-001", "ses-01", "g1", seed=7)
+    assert [os.path.basename(p) for p in out] == [
+        "convergence_20_random_voxels_colored_by_t2_sub-001_ses-01_sim-g1_gaussian.png",
+        "step_size_convergence_20_random_voxels_colored_by_t2_sub-001_ses-01_sim-g1.png",
+        "scatter_iterations_vs_loss_colored_by_t2_sub-001_ses-01_sim-g1.png"]
+    assert all(os.path.getsize(p) > 1000 for p in out)
+    m = min(len(idx), 50) + min(len(idx), 20)
+    assert seen["rows"].shape == (m, len(te)) and seen["rows"].dtype == np.float32
+    # the gathered rows are rows of the (N, nTE) stack at sampled mask indices
+    stack = np.stack([v.reshape(-1) for v in vols], axis=1).astype(np.float32)
+    assert all(any(np.array_equal(r, stack[i]) for i in idx) for r in seen["rows"][:5])

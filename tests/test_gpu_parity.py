@@ -125,6 +125,71 @@ def test_volume_seam_layouts_masks_and_residuals(t2):
     assert np.allclose(a.r2.reshape(-1)[idx], r2, rtol=1e-3, atol=1e-3)
 
 
+def test_loglin_closed_form_volume(t2):
+    """T2FIT_SOLVER_LOGLIN (BASELINE.json config 2's "2-param log-linear fit"; extension, the reference has no
+    such routine: parity with the reference unpinned).  HIP against the closed-form oracle on a seeded volume:
+    T2 and k within 1e-4 relative (float32 logarithm), zeros outside the mask bit-exact, residual map from the
+    float32 maps within RES_TOL; and the same voxels through every code path of the library -- 4 voxels per lane
+    (TE-major, N % 4 == 0), one voxel per lane (ragged N), voxel-major stack, slabs -- bit-identical."""
+    import torch
+
+    from fetal_t2mapping_amd import _abi, synth
+    from oracle import t2fit_oracle as O
+
+    for prior in (True, False):
+        echoes, mask, te = synth.brain_volume((6, 20, 36), 6, seed=21 + prior)
+        table = t2.fit_table("gaussian", True)
+        a = t2.fit_volume(echoes, mask, te, "gaussian", table, prior=prior, solver="loglin", extras=True)
+        n = mask.size
+        rows = echoes.reshape(6, n).T
+        idx = np.flatnonzero(mask.reshape(-1))
+        want, ok = O.loglinear_fit(rows[idx], te, table, prior=prior)
+        assert np.allclose(a.t2.reshape(-1)[idx], want[:, 1], rtol=1e-4)
+        assert np.allclose(a.k.reshape(-1)[idx], want[:, 0], rtol=1e-4)
+        assert np.array_equal(a.status.reshape(-1)[idx] == _abi.ST_CONVERGED, ok)
+        out = mask.reshape(-1) == 0
+        for name in ("t2", "k", "sigma", "res", "r2", "fun"):
+            assert np.all(getattr(a, name).reshape(-1)[out] == 0)
+        assert np.all(a.sigma == 0) and np.all(a.nit == 0) and np.all(a.status.reshape(-1)[out] == _abi.ST_MASKED)
+        res = O.compute_residuals(rows, te, "gaussian", False, a.k.reshape(-1), a.t2.reshape(-1), a.sigma.reshape(-1),
+                                  np.zeros(n, np.float32), idx)
+        assert np.max(np.abs(res - a.res.reshape(-1))) <= RES_TOL
+        fun = np.mean((rows[idx].astype(np.float64) - a.k.reshape(-1)[idx, None].astype(np.float64)
+                       * np.exp(-te[None, :] / a.t2.reshape(-1)[idx, None].astype(np.float64))) ** 2, axis=1)
+        assert np.allclose(a.fun.reshape(-1)[idx], fun, rtol=1e-3)
+        # ragged N (drop 3 voxels): one voxel per lane
+        cut = n - 3
+        b = t2.fit_volume(np.ascontiguousarray(echoes.reshape(6, n)[:, :cut]).reshape(6, 1, 1, cut),
+                          mask.reshape(-1)[:cut].reshape(1, 1, cut), te, "gaussian", table, prior=prior, solver="loglin")
+        # voxel-major stack
+        c = t2.fit_volume(np.ascontiguousarray(np.moveaxis(echoes, 0, -1)), mask, te, "gaussian", table, prior=prior,
+                          solver="loglin", layout="voxel_major")
+        # device entry, second half of the volume as its own slab
+        h = n // 2
+        d = t2.fit_volume(torch.from_numpy(np.ascontiguousarray(echoes.reshape(6, n)[:, h:])).cuda().reshape(6, 1, 1, n - h),
+                          torch.from_numpy(np.ascontiguousarray(mask.reshape(-1)[h:])).cuda(), te, "gaussian", table,
+                          prior=prior, solver="loglin")
+        torch.cuda.synchronize()
+        for name in ("t2", "k", "sigma", "res"):
+            full = getattr(a, name).reshape(-1)
+            assert np.array_equal(getattr(b, name).reshape(-1), full[:cut])
+            assert np.array_equal(getattr(c, name).reshape(-1), full)
+            assert np.array_equal(getattr(d, name).reshape(-1).cpu().numpy(), full[h:])
+    # the closed form exists for the 2-parameter model only
+    with pytest.raises(ValueError):
+        t2.fit_volume(echoes, mask, te, "gaussian_rician", t2.fit_table("gaussian_rician", True), solver="loglin")
+    # voxel seam + golden edge rows: infeasible / non-finite rows flagged as by the other solvers; on a
+    # noise-free decay inside the bounds the closed form meets the reference's converged 2-parameter fit
+    g = np.load(os.path.join(GOLDEN, "voxels_lf_gaussian_noprior_te8.npz"))
+    x, okv, nit, fun, st = t2.fit_voxels(np.arange(g["y"].shape[0]), "gaussian", _table(t2, g), g["te"], g["y"], False,
+                                         False, solver="loglin")
+    assert np.array_equal(st == _abi.ST_INFEASIBLE, g["raised"])
+    nonfinite = ~np.isfinite(g["y"]).all(axis=1) & ~g["raised"]
+    assert np.all(st[nonfinite] == _abi.ST_NONFINITE) and np.allclose(x[nonfinite][:, :2], g["x"][nonfinite])
+    i = [str(s) for s in g["edge_names"]].index("clean_wm")
+    assert abs(x[i, 1] - g["x"][i, 1]) < 2e-2 and abs(x[i, 0] - g["x"][i, 0]) / g["x"][i, 0] < 1e-3
+
+
 def test_union_mask_and_indices_bit_exact(t2):
     import torch
 
@@ -312,6 +377,63 @@ def test_cli_driver_on_device(t2, tmp_path):
     assert np.all(t2img.arr[label == 0] == 0)
     csv = [f for f in os.listdir(os.path.dirname(list(sitk.written)[0])) if f.endswith(".csv")]
     assert csv == ["sub-001_ses-01_recon_1mm_sim-p1_ROI_data_ada-gaussian.csv"]
+
+
+def test_cli_main_config1_on_nifti_files(t2, tmp_path, monkeypatch):
+    """BASELINE.json config 1 (NIST phantom 64x64x20 x 6 TE, --in_vitro) through the whole command line on
+    real .nii.gz files: metadata CSV -> concurrent NIfTI decode -> device union mask -> HIP fit -> NIfTI maps
+    + ROI CSV.  Maps equal a direct fit_volume call on the same arrays bit for bit, geometry is carried over
+    from the last reconstruction, the CSV holds the per-vial nanmean / nanstd (utils/t2map_utils.py:30-59)."""
+    import sys
+
+    import pandas as pd
+
+    from fetal_t2mapping_amd import cli as R
+    from fetal_t2mapping_amd import nifti, synth
+
+    monkeypatch.setitem(sys.modules, "SimpleITK", None)  # the image has none; an earlier test may have faked one
+    echoes, mask, label, te, gt = synth.phantom_volume()
+    root = str(tmp_path)
+    bids = os.path.join(root, "projects") + "/"
+    os.makedirs(os.path.join(bids, "prj-901"))
+    os.makedirs(os.path.join(root, "dicom", "logs"))
+    D = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    rows = []
+    for i, t in enumerate(te):
+        acq = {"prj": "prj-901", "sub": "sub-007", "ses": "ses-02", "run": f"run-{i + 1:02d}", "EchoTime": t / 1000.0,
+               "CoilString": "HeadNeck"}
+        rows.append(acq)
+        for arr, dirname in ((echoes[i], R.recon_dirname), (mask, R.mask_dirname), (label, R.phantom_labels_dirname)):
+            img = nifti.GetImageFromArray(arr)
+            img.SetSpacing((1.0, 1.0, 3.0)); img.SetOrigin((-32.0, 12.5, 7.0)); img.SetDirection(D.reshape(-1))
+            nifti.WriteImage(img, R.get_img_path(bids, acq, dirname).replace(" ", ""))
+    pd.DataFrame(rows).to_csv(os.path.join(root, "dicom", "logs", "log.csv"), index=False)
+    R.main(["--path", root, "--csv", "log.csv", "--in_vitro", "--gaussian", "--hf", "--sim", "c1", "--plots",
+            "--plot_seed", "3", "--TEs"] + [str(int(t)) for t in te])
+    figs = sorted(os.listdir(os.path.join(bids, "prj-901", "ada", "convergence_analysis")))
+    assert figs == ["convergence_20_random_voxels_colored_by_t2_sub-007_ses-02_sim-c1_gaussian.png",
+                    "scatter_iterations_vs_loss_colored_by_t2_sub-007_ses-02_sim-c1.png",
+                    "step_size_convergence_20_random_voxels_colored_by_t2_sub-007_ses-02_sim-c1.png"]
+    out_dir = os.path.join(bids, "prj-901", "derivatives", R.t2map_dirname, "sub-007", "ses-02", "anat")
+    stem = "sub-007_ses-02_recon_1mm_sim-c1_"
+    assert sorted(os.listdir(out_dir)) == sorted([stem + f"{m}map_ada-gaussian.nii.gz" for m in ("t2", "k", "sigma", "res")]
+                                                 + [stem + "ROI_data_ada-gaussian.csv"])
+    want = t2.fit_volume(echoes, mask, te, "gaussian", t2.fit_table("gaussian", False))
+    got = {}
+    for m in ("t2", "k", "sigma", "res"):
+        img = nifti.ReadImage(os.path.join(out_dir, stem + f"{m}map_ada-gaussian.nii.gz"))
+        assert img.arr.dtype == np.float32 and np.array_equal(img.arr, getattr(want, m), equal_nan=True), m
+        assert np.allclose(img.GetSpacing(), (1.0, 1.0, 3.0)) and np.allclose(img.GetOrigin(), (-32.0, 12.5, 7.0))
+        assert np.allclose(img.GetDirection(), D.reshape(-1), atol=1e-6)
+        got[m] = img.arr
+    csv = pd.read_csv(os.path.join(out_dir, stem + "ROI_data_ada-gaussian.csv"))
+    assert len(csv) == len(gt)
+    for i in range(len(gt)):
+        sel = label == i + 1
+        assert np.isclose(csv["meanT2"][i], np.nanmean(got["t2"][sel])) and np.isclose(csv["stdT2"][i], np.nanstd(got["t2"][sel]))
+        assert np.isclose(csv["meanK"][i], np.nanmean(got["k"][sel]))
+    # long-T2 vials are recovered (short ones have decayed before the first echo at 114 ms)
+    assert abs(csv["meanT2"][3] - gt[3]) < 0.1 * gt[3]
 
 
 def test_streamed_subjects_equal_per_subject_fits(t2):

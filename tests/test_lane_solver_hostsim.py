@@ -60,3 +60,41 @@ def test_residual_map_matches_reference():
         res = sim.residuals(cfg, d["y"][rows], x[:, 0], x[:, 1], sg)
         assert np.mean(res == d["res"][rows]) >= 0.9, path
         assert np.max(np.abs(res - d["res"][rows])) <= 1e-3, path
+
+
+@pytest.mark.parametrize("path", [f for f in FILES if "_gaussian_prior_" in f or "_gaussian_noprior_" in f],
+                         ids=lambda p: os.path.basename(p)[7:-4])
+def test_loglin_lane_equals_closed_form_oracle(path):
+    """T2FIT_SOLVER_LOGLIN (extension named by BASELINE.json config 2; the reference has no log-linear
+    routine, so parity with it is unpinned): the lane code must equal the closed form of
+    oracle.loglinear_fit -- float64 sums over a float32 logarithm, so T2 within 1e-4 relative -- and
+    recover a noise-free decay inside the bounds, where it also meets the reference's converged fit."""
+    from oracle import t2fit_oracle as oracle
+
+    d = np.load(path)
+    prior = bool(d["prior"])
+    table = oracle.fit_table("gaussian", bool(d["low_field"]))
+    cfg = sim.config("gaussian", bool(d["low_field"]), d["te"], prior=prior, solver="loglin")
+    o = sim.fit_rows(cfg, d["y"])
+    rows = np.where(~d["raised"] & np.all(np.isfinite(d["y"]), axis=1))[0]
+    want, ok = oracle.loglinear_fit(d["y"][rows], d["te"], table, prior=prior)
+    got = o["x"][rows]
+    assert np.array_equal(o["status"][rows] == 1, ok)
+    assert np.all(o["nit"][rows] == 0) and np.all(got[:, 2] == 0)
+    assert np.allclose(got[:, 1], want[:, 1], rtol=1e-4, atol=1e-6)
+    assert np.allclose(got[:, 0], want[:, 0], rtol=1e-4, atol=1e-6)
+    # rows scipy refuses (lb > ub) and non-finite rows behave as in the other solvers
+    assert np.array_equal(o["status"] == 4, d["raised"])
+    bad = ~d["raised"] & ~np.all(np.isfinite(d["y"]), axis=1)
+    assert np.all(o["status"][bad] == 3) and np.allclose(o["x"][bad][:, :2], d["x"][bad])
+    # noise-free white-matter decay (k 1000, T2 110 ms): exact, and equal to the reference's result
+    names = [str(n) for n in d["edge_names"]]
+    i = names.index("clean_wm")
+    if prior or d["y"][i, 0] <= 1000.0:
+        assert abs(o["x"][i, 1] - 110.0) < 1e-2 and abs(o["x"][i, 0] - 1000.0) < 0.2
+        assert abs(o["x"][i, 1] - d["x"][i, 1]) < 2e-2
+    # objective value reported is the reference's objective at the returned point
+    te = d["te"]
+    for r in rows[:20]:
+        f = np.mean((d["y"][r].astype(np.float64) - o["x"][r, 0] * np.exp(-te / o["x"][r, 1])) ** 2)
+        assert np.isclose(o["fun"][r], f, rtol=1e-12)
