@@ -5,8 +5,8 @@ Drop-in for the voxel-wise fitting path of Medical-Image-Analysis-Laboratory/fet
 in hand-written HIP kernels (csrc/) behind the C ABI of include/t2fit.h; this package is the
 Python host side that mirrors the reference's function surface.  There is no CPU execution path.
 """
-from .t2map import (T2Maps, compute_residuals, fit_table, fit_volume, fit_voxel, fit_voxels, fit_voxels_trace, make_config,
-                    set_fit_params, stack_mask_flatten, union_mask_dev)
+from .t2map import (T2Maps, compute_residuals, fit_table, fit_volume, fit_voxel, fit_voxels, fit_voxels_trace, label_stats,
+                    make_config, set_fit_params, stack_mask_flatten, union_mask_dev)
 
-__all__ = ["T2Maps", "compute_residuals", "fit_table", "fit_volume", "fit_voxel", "fit_voxels", "fit_voxels_trace", "make_config",
+__all__ = ["T2Maps", "compute_residuals", "fit_table", "fit_volume", "fit_voxel", "fit_voxels", "fit_voxels_trace", "label_stats", "make_config",
            "set_fit_params", "stack_mask_flatten", "union_mask_dev"]

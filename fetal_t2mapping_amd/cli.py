@@ -130,17 +130,15 @@ def save_nifti_maps(t2_map, k_map, sigma_map, res_map, dirname, recon_img, bids_
     print(f"T2 map saved as nifti file in {dirname}")
 
 
-def save_phantom_csv(t2_map, k_map, sigma_map, label, id, gt, bids_path, acq, dirname, sim, analysis):
-    """utils/t2map_utils.py:30-59: nanmean / nanstd of each map per vial label."""
+def save_phantom_csv(t2_map, k_map, sigma_map, label, id, gt, bids_path, acq, dirname, sim, analysis, device=0):
+    """utils/t2map_utils.py:30-59: nanmean / nanstd of each map per vial label, reduced on the GPU
+    (t2fit_label_stats_dev: mean, then mean squared deviation from it, as numpy computes them)."""
     import pandas as pd
 
     n_roi = len(gt)
-    cols = {name: np.zeros(n_roi) for name in ("meanT2", "stdT2", "meanK", "stdK", "meanC", "stdC")}
-    for i in range(n_roi):
-        sel = label == i + 1
-        for arr, m, s in ((t2_map, "meanT2", "stdT2"), (k_map, "meanK", "stdK"), (sigma_map, "meanC", "stdC")):
-            cols[m][i] = np.nanmean(arr[sel])
-            cols[s][i] = np.nanstd(arr[sel])
+    cols = {}
+    for arr, m, s in ((t2_map, "meanT2", "stdT2"), (k_map, "meanK", "stdK"), (sigma_map, "meanC", "stdC")):
+        cols[m], cols[s], _ = t2map.label_stats(arr, label, n_roi, device=device)
     df = pd.DataFrame({"id": id, "trueT2": gt, **cols})
     path = get_img_path(bids_path, acq.iloc[0], dirname).replace("t2map.nii.gz", f"sim-{sim}_ROI_data_ada-{analysis}.csv")
     df.to_csv(path, index=False)
@@ -213,7 +211,8 @@ def process_t2maps(metadata, bids_path, TEs, fit, fit_params, phantom, low_field
                 # the reference unpacks (gt, id) as id, gt (run_t2mapping.py:27 vs :478), which swaps the
                 # CSV's `id` and `trueT2` columns; kept so the output file is identical
                 id_, gt_ = set_phantom_gt(low_field)
-                save_phantom_csv(t2_map, k_map, sigma_map, label, id_, gt_, bids_path, acq, t2map_dirname, sim, fit)
+                save_phantom_csv(t2_map, k_map, sigma_map, label, id_, gt_, bids_path, acq, t2map_dirname, sim, fit,
+                                 device=device)
 
 
 _EXCLUSIVE_GROUPS = (

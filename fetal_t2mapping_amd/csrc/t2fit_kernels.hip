@@ -157,6 +157,9 @@ __global__ __launch_bounds__(kBlock) void fit_volume_kernel(const LaneParams P, 
 constexpr int kLoglinVec = 4;
 constexpr int kLoglinTile = kBlock * kLoglinVec;
 
+// kExtras = false is the four-map form (no r2 / se / fun / nit / status / float64 outputs): its code holds none
+// of those evaluations, which keeps the four unrolled voxel bodies inside the instruction cache.
+template <bool kExtras>
 __global__ __launch_bounds__(kBlock) void loglin_volume_kernel(const LaneParams P, const float* __restrict__ echoes,
                                                                const uint8_t* __restrict__ mask, int64_t n_vox,
                                                                DevMaps m) {
@@ -171,6 +174,9 @@ __global__ __launch_bounds__(kBlock) void loglin_volume_kernel(const LaneParams 
     act[0] = mk.x != 0; act[1] = mk.y != 0; act[2] = mk.z != 0; act[3] = mk.w != 0;
   }
   const bool any = act[0] || act[1] || act[2] || act[3];
+  // finite check, first sample and row maximum are taken while the samples are still in registers
+  bool fin[kLoglinVec] = {true, true, true, true};
+  float ymax[kLoglinVec] = {0.0f, 0.0f, 0.0f, 0.0f}, y0[kLoglinVec] = {0.0f, 0.0f, 0.0f, 0.0f};
   if (any) {
     const float* src = echoes + v0;
     for (int i0 = 0; i0 < n_te; i0 += 8) {  // up to eight 16-byte loads in flight per lane
@@ -182,31 +188,49 @@ __global__ __launch_bounds__(kBlock) void loglin_volume_kernel(const LaneParams 
       for (int j = 0; j < 8; ++j)
         if (i0 + j < n_te) {
           float* dst = lds + (i0 + j) * kLoglinTile + lane;
-          dst[0] = tmp[j].x; dst[kBlock] = tmp[j].y; dst[2 * kBlock] = tmp[j].z; dst[3 * kBlock] = tmp[j].w;
+          const float sv[kLoglinVec] = {tmp[j].x, tmp[j].y, tmp[j].z, tmp[j].w};
+#pragma unroll
+          for (int q = 0; q < kLoglinVec; ++q) {
+            dst[q * kBlock] = sv[q];
+            fin[q] = fin[q] && t2_finite(sv[q]);
+            if (i0 + j == 0) { y0[q] = sv[q]; ymax[q] = sv[q]; }
+            ymax[q] = sv[q] > ymax[q] ? sv[q] : ymax[q];
+          }
         }
     }
   }
   float o_t2[kLoglinVec], o_k[kLoglinVec], o_res[kLoglinVec];
-  const bool want_fun = m.fun != nullptr || m.fund != nullptr;
+  const bool want_fun = kExtras && (m.fun != nullptr || m.fund != nullptr);
 #pragma unroll
   for (int q = 0; q < kLoglinVec; ++q) {
     o_t2[q] = 0.0f; o_k[q] = 0.0f; o_res[q] = 0.0f;
     const int64_t v = v0 + q;
     if (!act[q]) {
-      if (m.r2) m.r2[v] = 0.0f;
-      if (m.se) m.se[v] = 0.0f;
-      if (m.fun) m.fun[v] = 0.0f;
-      if (m.nit) m.nit[v] = 0;
-      if (m.status) m.status[v] = T2FIT_ST_MASKED;
-      if (m.xd) { m.xd[3 * v] = 0.0; m.xd[3 * v + 1] = 0.0; m.xd[3 * v + 2] = 0.0; }
-      if (m.fund) m.fund[v] = 0.0;
+      if constexpr (kExtras) {
+        if (m.r2) m.r2[v] = 0.0f;
+        if (m.se) m.se[v] = 0.0f;
+        if (m.fun) m.fun[v] = 0.0f;
+        if (m.nit) m.nit[v] = 0;
+        if (m.status) m.status[v] = T2FIT_ST_MASKED;
+        if (m.xd) { m.xd[3 * v] = 0.0; m.xd[3 * v + 1] = 0.0; m.xd[3 * v + 2] = 0.0; }
+        if (m.fund) m.fund[v] = 0.0;
+      }
       continue;
     }
-    bool finite;
-    float y0_raw;
-    const ObjCtx c = prepare_samples(P, lds + q * kBlock + lane, kLoglinTile, finite, y0_raw);
+    float* col = lds + q * kBlock + lane;
+    bool finite = fin[q];
+    if (P.norm) {  // run_t2mapping.py:237-238: float32 / float32, as prepare_samples() does it
+      for (int i = 0; i < n_te; ++i) {
+        const float sv = col[i * kLoglinTile] / ymax[q];
+        col[i * kLoglinTile] = sv;
+        finite = finite && t2_finite(sv);
+      }
+    }
+    ObjCtx c;
+    c.P = &P;
+    c.y = EchoView{col, kLoglinTile};
     double lb[3], ub[3];
-    const bool feasible = lane_bounds(P, y0_raw, lb, ub);
+    const bool feasible = lane_bounds(P, y0[q], lb, ub);
     LaneResult r;
     r.nit = 0; r.nfev = 0; r.fun = NAN;
     if (!feasible) {
@@ -219,15 +243,17 @@ __global__ __launch_bounds__(kBlock) void loglin_volume_kernel(const LaneParams 
       loglin_solve(c, lb, ub, want_fun, r);
     }
     LaneOutputs o;
-    lane_epilogue(c, r, o, m.r2 != nullptr, m.se != nullptr);
+    lane_epilogue(c, r, o, kExtras && m.r2 != nullptr, kExtras && m.se != nullptr);
     o_t2[q] = o.t2; o_k[q] = o.k; o_res[q] = o.res;
-    if (m.r2) m.r2[v] = o.r2;
-    if (m.se) m.se[v] = o.se;
-    if (m.fun) m.fun[v] = o.fun;
-    if (m.nit) m.nit[v] = o.nit;
-    if (m.status) m.status[v] = o.status;
-    if (m.xd) { m.xd[3 * v] = r.x[0]; m.xd[3 * v + 1] = r.x[1]; m.xd[3 * v + 2] = r.x[2]; }
-    if (m.fund) m.fund[v] = r.fun;
+    if constexpr (kExtras) {
+      if (m.r2) m.r2[v] = o.r2;
+      if (m.se) m.se[v] = o.se;
+      if (m.fun) m.fun[v] = o.fun;
+      if (m.nit) m.nit[v] = o.nit;
+      if (m.status) m.status[v] = o.status;
+      if (m.xd) { m.xd[3 * v] = r.x[0]; m.xd[3 * v + 1] = r.x[1]; m.xd[3 * v + 2] = r.x[2]; }
+      if (m.fund) m.fund[v] = r.fun;
+    }
   }
   *reinterpret_cast<float4*>(m.t2 + v0) = make_float4(o_t2[0], o_t2[1], o_t2[2], o_t2[3]);
   *reinterpret_cast<float4*>(m.k + v0) = make_float4(o_k[0], o_k[1], o_k[2], o_k[3]);
@@ -557,6 +583,63 @@ __global__ __launch_bounds__(kBlock) void mask_write_kernel(const uint8_t* __res
     if (f[q]) idx_out[pos++] = v0 + q;
 }
 
+// ---- per-label statistics of a map (utils/t2map_utils.py:43-53: nanmean / nanstd per vial) -------
+// Two rounds, numpy's own algorithm: mean first, then the mean of squared deviations from it (a
+// constant region gives exactly 0).  Deterministic: each thread tallies its strided share of the
+// workgroup's contiguous span into its own LDS column (one slot per label), columns are combined by a
+// fixed tree, and the per-workgroup partials are added in workgroup order by one thread per label.
+constexpr int kMaxLabels = 32;  // 2 * 32 * 256 doubles of LDS = 128 KiB (the NIST phantom has 14 vials)
+
+template <bool kSecond>
+__global__ __launch_bounds__(kBlock) void label_partial_kernel(const float* __restrict__ map,
+                                                               const int32_t* __restrict__ label, int64_t n_vox,
+                                                               int n_labels, int64_t span, const double* __restrict__ mean,
+                                                               double* __restrict__ part_sum, int64_t* __restrict__ part_cnt) {
+  extern __shared__ double acc[];  // [n_labels][kBlock] sums, then [n_labels][kBlock] counts (as double)
+  double* cnt = acc + (size_t)n_labels * kBlock;
+  const int tid = threadIdx.x;
+  for (int l = 0; l < n_labels; ++l) { acc[l * kBlock + tid] = 0.0; cnt[l * kBlock + tid] = 0.0; }
+  const int64_t lo = (int64_t)blockIdx.x * span;
+  const int64_t hi = lo + span < n_vox ? lo + span : n_vox;
+  for (int64_t v = lo + tid; v < hi; v += kBlock) {
+    const int32_t l = label[v] - 1;
+    const float x = map[v];
+    if (l >= 0 && l < n_labels && x == x) {  // NaN values are skipped, as nanmean / nanstd do
+      double t = (double)x;
+      if (kSecond) { t -= mean[l]; t *= t; }
+      acc[l * kBlock + tid] += t;
+      cnt[l * kBlock + tid] += 1.0;
+    }
+  }
+  __syncthreads();
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
+    if (tid < off)
+      for (int l = 0; l < n_labels; ++l) {
+        acc[l * kBlock + tid] += acc[l * kBlock + tid + off];
+        cnt[l * kBlock + tid] += cnt[l * kBlock + tid + off];
+      }
+    __syncthreads();
+  }
+  if (tid < n_labels) {
+    part_sum[(size_t)blockIdx.x * n_labels + tid] = acc[tid * kBlock];
+    part_cnt[(size_t)blockIdx.x * n_labels + tid] = (int64_t)cnt[tid * kBlock];
+  }
+}
+
+// kSecond = false: mean_out = sum / count; true: std_out = sqrt(sum of squared deviations / count)
+template <bool kSecond>
+__global__ void label_final_kernel(const double* __restrict__ part_sum, const int64_t* __restrict__ part_cnt, int n_blocks,
+                                   int n_labels, double* __restrict__ out, int64_t* __restrict__ count_out) {
+  const int l = threadIdx.x;
+  if (l >= n_labels) return;
+  double s = 0.0;
+  int64_t c = 0;
+  for (int b = 0; b < n_blocks; ++b) { s += part_sum[(size_t)b * n_labels + l]; c += part_cnt[(size_t)b * n_labels + l]; }
+  const double m = c > 0 ? s / (double)c : (double)NAN;  // numpy: mean of an empty slice is NaN
+  out[l] = kSecond ? sqrt(m) : m;
+  if (count_out) count_out[l] = c;
+}
+
 // ---- launch helpers -----------------------------------------------------------------------------
 using FitKernel = void (*)(const LaneParams, const float*, int, const uint8_t*, int64_t, DevMaps);
 
@@ -667,7 +750,9 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
     hipLaunchKernelGGL(residuals_kernel, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox,
                        (const float*)dm.t2, (const float*)dm.k, (const float*)dm.sigma, dm.res, dm.r2, dm.se);
   } else if (loglin && loglin_vec_ok(echoes, layout, mask, n_vox, dm, cfg->n_te)) {
-    hipLaunchKernelGGL(loglin_volume_kernel, dim3((unsigned)((n_vox + kLoglinTile - 1) / kLoglinTile)), dim3(kBlock),
+    const bool extras = dm.r2 || dm.se || dm.fun || dm.nit || dm.status || dm.xd || dm.fund;
+    hipLaunchKernelGGL(extras ? loglin_volume_kernel<true> : loglin_volume_kernel<false>,
+                       dim3((unsigned)((n_vox + kLoglinTile - 1) / kLoglinTile)), dim3(kBlock),
                        (size_t)cfg->n_te * kLoglinTile * sizeof(float), st, P, echoes, mask, n_vox, dm);
   } else {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox, dm);
@@ -911,6 +996,36 @@ int t2fit_residuals_dev(const t2fit_config* cfg, const float* echoes_dev, int la
   hipLaunchKernelGGL(residuals_kernel, dim3(grid), dim3(kBlock), lds, (hipStream_t)stream, P, echoes_dev, layout,
                      mask_dev, n_vox, t2, k, sigma, res, (float*)nullptr, (float*)nullptr);
   T2_HIP(hipGetLastError());
+  return T2FIT_OK;
+}
+
+int t2fit_label_stats_dev(const float* map_dev, const int32_t* label_dev, int64_t n_vox, int n_labels, double* mean_out,
+                          double* std_out, int64_t* count_out, void* stream) {
+  if (!map_dev || !label_dev || !mean_out || !std_out) return fail(T2FIT_E_INVALID, "NULL pointer");
+  if (n_vox < 0 || n_labels < 1 || n_labels > kMaxLabels) return fail(T2FIT_E_INVALID, "n_vox < 0 or n_labels outside 1..32");
+  hipStream_t st = (hipStream_t)stream;
+  const int n_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n_vox + 8 * kBlock - 1) / (8 * kBlock)));
+  const int64_t span = (n_vox + n_blocks - 1) / n_blocks;
+  double* part_sum = nullptr;
+  int64_t* part_cnt = nullptr;
+  T2_HIP(hipMallocAsync((void**)&part_sum, (size_t)n_blocks * n_labels * sizeof(double), st));
+  T2_HIP(hipMallocAsync((void**)&part_cnt, (size_t)n_blocks * n_labels * sizeof(int64_t), st));
+  const size_t lds = (size_t)2 * n_labels * kBlock * sizeof(double);
+  auto k1 = label_partial_kernel<false>;
+  auto k2 = label_partial_kernel<true>;
+  T2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  T2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k1, dim3(n_blocks), dim3(kBlock), lds, st, map_dev, label_dev, n_vox, n_labels, span,
+                     (const double*)nullptr, part_sum, part_cnt);
+  hipLaunchKernelGGL(label_final_kernel<false>, dim3(1), dim3(kMaxLabels), 0, st, (const double*)part_sum,
+                     (const int64_t*)part_cnt, n_blocks, n_labels, mean_out, count_out);
+  hipLaunchKernelGGL(k2, dim3(n_blocks), dim3(kBlock), lds, st, map_dev, label_dev, n_vox, n_labels, span,
+                     (const double*)mean_out, part_sum, part_cnt);
+  hipLaunchKernelGGL(label_final_kernel<true>, dim3(1), dim3(kMaxLabels), 0, st, (const double*)part_sum,
+                     (const int64_t*)part_cnt, n_blocks, n_labels, std_out, (int64_t*)nullptr);
+  T2_HIP(hipGetLastError());
+  T2_HIP(hipFreeAsync(part_sum, st));
+  T2_HIP(hipFreeAsync(part_cnt, st));
   return T2FIT_OK;
 }
 

@@ -177,6 +177,32 @@ T2_HD bool lane_bounds(const LaneParams& P, float y0_raw, double* lb, double* ub
   return ok;
 }
 
+// exp(x) for the residual map, where the float64 prediction is rounded to float32 straight away
+// (utils/t2map_utils.py:77-80 stores it into a float32 array): round-to-nearest range reduction by
+// ln 2 in two pieces, degree-11 Taylor polynomial on |r| <= 0.347 (truncation 6e-15 relative), scale by
+// 2^n.  A few ulp of float64 instead of the library's < 1 ulp at about a third of its instructions; the
+// float32 rounding of the prediction flips for about one sample in 10^7.  NaN propagates; arguments
+// below -746 (including -inf) give 0.  Not used inside any solver.
+T2_HD double t2_exp_res(double x) {
+  const double n = nearbyint(x * 1.4426950408889634);
+  double r = fma(n, -6.93147180369123816490e-01, x);
+  r = fma(n, -1.90821492927058770002e-10, r);
+  double p = 2.50521083854417187751e-08;           // 1/11!
+  p = fma(p, r, 2.75573192239858906526e-07);       // 1/10!
+  p = fma(p, r, 2.75573192239858906526e-06);       // 1/9!
+  p = fma(p, r, 2.48015873015873015873e-05);       // 1/8!
+  p = fma(p, r, 1.98412698412698412698e-04);       // 1/7!
+  p = fma(p, r, 1.38888888888888888889e-03);       // 1/6!
+  p = fma(p, r, 8.33333333333333333333e-03);       // 1/5!
+  p = fma(p, r, 4.16666666666666666667e-02);       // 1/4!
+  p = fma(p, r, 1.66666666666666666667e-01);       // 1/3!
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  const double nc = n < -2000.0 ? -2000.0 : (n > 2000.0 ? 2000.0 : n);  // keeps the int conversion defined
+  return x < -746.0 ? 0.0 : ldexp(p, (int)nc);  // exp(-inf) = 0 (a T2 of 0 ms handed to the residual entry point)
+}
+
 // a / b from r = 1/b (correctly rounded) with one residual correction: the correctly rounded quotient
 // except for rare last-bit cases, at three FMA-class operations instead of an IEEE division sequence
 T2_HD double t2_div_by_rcp(double a, double b, double r) {
@@ -195,8 +221,8 @@ T2_HD float residual_mean(const ObjCtx& c, float k32, float t232, float s32) {
   auto resid = [&](int i) {
     const double te = c.P->te[i];
     double pred;
-    if (gauss) pred = k * t2_exp(t2_div_by_rcp(-te, t2, rt2));
-    else pred = t2_sqrt(k2 * t2_exp(t2_div_by_rcp(-2.0 * te, t2, rt2)) + s2);
+    if (gauss) pred = k * t2_exp_res(t2_div_by_rcp(-te, t2, rt2));
+    else pred = t2_sqrt(k2 * t2_exp_res(t2_div_by_rcp(-2.0 * te, t2, rt2)) + s2);
     return c.sample(i) - (float)pred;
   };
   // numpy float32 add.reduce over a contiguous row: n < 8 sequential from 0; otherwise eight

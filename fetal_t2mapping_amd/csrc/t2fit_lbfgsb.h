@@ -344,9 +344,10 @@ struct Lbfgsb {
     NpSum s0, s1, s2, s3;
     if constexpr (MODEL == T2FIT_MODEL_GAUSSIAN) {
       const double k = x[0], t2 = x[1], kp = x1[0], t2p = x1[1];
+      const double rt2 = 1.0 / t2, rt2p = 1.0 / t2p;  // one IEEE division per T2, shared by every echo
       auto body = [&](int i, auto add) {
         const double y = (double)c.sample(i), te = P.te[i];
-        const double E = t2_exp(-te / t2), Ep = t2_exp(-te / t2p);
+        const double E = t2_exp(t2_div_by_rcp(-te, t2, rt2)), Ep = t2_exp(t2_div_by_rcp(-te, t2p, rt2p));
         const double r0 = y - k * E, r1 = y - kp * E, r2 = y - k * Ep;
         add(r0 * r0, r1 * r1, r2 * r2, 0.0);
       };
@@ -361,9 +362,10 @@ struct Lbfgsb {
     } else if constexpr (MODEL == T2FIT_MODEL_GAUSSIAN_RICIAN) {
       const double k2 = x[0] * x[0], kp2 = x1[0] * x1[0], t2 = x[1], t2p = x1[1];
       const double sg2 = x[N - 1] * x[N - 1], sgp2 = x1[N - 1] * x1[N - 1];
+      const double rt2 = 1.0 / t2, rt2p = 1.0 / t2p;
       auto body = [&](int i, auto add) {
         const double y = (double)c.sample(i), te = P.te[i];
-        const double E = t2_exp(-2.0 * te / t2), Ep = t2_exp(-2.0 * te / t2p);
+        const double E = t2_exp(t2_div_by_rcp(-2.0 * te, t2, rt2)), Ep = t2_exp(t2_div_by_rcp(-2.0 * te, t2p, rt2p));
         const double r0 = y - t2_sqrt(k2 * E + sg2), r1 = y - t2_sqrt(kp2 * E + sg2);
         const double r2 = y - t2_sqrt(k2 * Ep + sg2), r3 = y - t2_sqrt(k2 * E + sgp2);
         add(r0 * r0, r1 * r1, r2 * r2, r3 * r3);
@@ -381,6 +383,7 @@ struct Lbfgsb {
       const double k = x[0], kp = x1[0], t2 = x[1], t2p = x1[1];
       const double sg2 = x[N - 1] * x[N - 1], sgp2 = x1[N - 1] * x1[N - 1];
       const double ls2 = t2_log(sg2), lsp2 = t2_log(sgp2);
+      const double rt2 = 1.0 / t2, rt2p = 1.0 / t2p;
       auto term = [](double kk, double E, double s2v, double ls2v, float yf) {
         const double m = kk * E;
         const double xx = (m * (double)yf) / s2v;
@@ -392,7 +395,7 @@ struct Lbfgsb {
       auto body = [&](int i, auto add) {
         const float yf = c.sample(i);
         const double te = P.te[i];
-        const double E = t2_exp(-te / t2), Ep = t2_exp(-te / t2p);
+        const double E = t2_exp(t2_div_by_rcp(-te, t2, rt2)), Ep = t2_exp(t2_div_by_rcp(-te, t2p, rt2p));
         add(term(k, E, sg2, ls2, yf), term(kp, E, sg2, ls2, yf), term(k, Ep, sg2, ls2, yf), term(k, E, sgp2, lsp2, yf));
       };
       static_for<0, 8>([&](auto JC) {

@@ -32,20 +32,23 @@ T2_HD bool loglin_closed_form(const ObjCtx& c, double& k, double& t2) {
   float ypiv = c.sample(0);
   for (int i = 0; i < P.n_te; ++i) {
     const float yf = c.sample(i);
-    if (yf > ypiv) { ypiv = yf; piv = i; }
+    const bool up = yf > ypiv;
+    ypiv = up ? yf : ypiv;
+    piv = up ? i : piv;
     cnt += yf > 0.0f;
   }
   if (cnt < 2) return false;
   const double tp = P.te[piv], lp = (double)t2_logf_precise(ypiv);
   double sw = 0.0, st = 0.0, sl = 0.0, stt = 0.0, stl = 0.0;
   for (int i = 0; i < P.n_te; ++i) {
+    // a sample <= 0 gets weight 0 and stands in as the pivot value (dl = 0): two selects instead of
+    // five conditional accumulations
     const float yf = c.sample(i);
-    if (yf > 0.0f) {
-      const double y = (double)yf, w = y * y;
-      const double dt = P.te[i] - tp, dl = (double)t2_logf_precise(yf) - lp;
-      const double wt = w * dt;
-      sw += w; st += wt; sl += w * dl; stt += wt * dt; stl += wt * dl;
-    }
+    const bool pos = yf > 0.0f;
+    const double y = (double)(pos ? yf : 0.0f), w = y * y;
+    const double dt = P.te[i] - tp, dl = (double)t2_logf_precise(pos ? yf : ypiv) - lp;
+    const double wt = w * dt;
+    sw += w; st += wt; sl += w * dl; stt += wt * dt; stl += wt * dl;
   }
   const double rsw = 1.0 / sw;
   const double sxx = stt - st * st * rsw, sxy = stl - st * sl * rsw;

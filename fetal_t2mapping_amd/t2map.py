@@ -156,6 +156,29 @@ def union_mask_dev(masks):
     return mask, idx, cnt
 
 
+def label_stats(map_, label, n_labels: int, device: int = 0):
+    """Per-label ``(nanmean, nanstd, count)`` of a map on the GPU: the loop of ``save_phantom_csv``
+    (utils/t2map_utils.py:43-53).  ``map_``: float32 array or CUDA tensor of any shape; ``label``: integer
+    array/tensor of the same shape, vials numbered 1..n_labels.  Returns float64 / int64 numpy arrays."""
+    import torch
+
+    lib = require_gpu()
+    dev = map_.device if type(map_).__module__.startswith("torch") and map_.is_cuda else torch.device("cuda", device)
+    m = (map_ if type(map_).__module__.startswith("torch") else torch.from_numpy(np.ascontiguousarray(map_, np.float32)))
+    m = m.to(dev, torch.float32).contiguous().reshape(-1)
+    lab = label if type(label).__module__.startswith("torch") else torch.from_numpy(np.ascontiguousarray(label).astype(np.int32))
+    lab = lab.to(dev, torch.int32).contiguous().reshape(-1)
+    if lab.numel() != m.numel():
+        raise ValueError("label shape does not match the map")
+    mean = torch.empty(n_labels, dtype=torch.float64, device=dev)
+    std = torch.empty(n_labels, dtype=torch.float64, device=dev)
+    cnt = torch.empty(n_labels, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.t2fit_label_stats_dev(m.data_ptr(), lab.data_ptr(), m.numel(), int(n_labels), mean.data_ptr(),
+                                        std.data_ptr(), cnt.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return mean.cpu().numpy(), std.cpu().numpy(), cnt.cpu().numpy()
+
+
 # --------------------------------------------------------------------------------------------
 # volume seam
 # --------------------------------------------------------------------------------------------

@@ -172,6 +172,17 @@ int t2fit_residuals_dev(const t2fit_config *cfg, const float *echoes_dev, int la
                         const uint8_t *mask_dev, int64_t n_vox, const float *t2, const float *k,
                         const float *sigma, float *res, void *stream);
 
+/* Phantom ROI statistics: replaces the per-vial nanmean / nanstd loop of save_phantom_csv
+ * (utils/t2map_utils.py:43-53) for a map that is on the device.
+ *   map_dev   : float32 [n_vox]
+ *   label_dev : int32 [n_vox]; voxels labelled 1..n_labels are tallied (n_labels <= 32), others ignored
+ *   mean_out, std_out : device float64 [n_labels]: mean and population standard deviation (ddof = 0) over
+ *               the non-NaN values of each label, NaN for a label without any (numpy's result)
+ *   count_out : device int64 [n_labels] or NULL: number of non-NaN values per label
+ * Asynchronous on `stream`; the result does not depend on the launch (fixed summation order). */
+int t2fit_label_stats_dev(const float *map_dev, const int32_t *label_dev, int64_t n_vox, int n_labels,
+                          double *mean_out, double *std_out, int64_t *count_out, void *stream);
+
 /* Duration in milliseconds of the last fit kernel launched by this thread's most recent
  * t2fit_volume_dev call with timing enabled (t2fit_set_timing(1)); measured with HIP events on
  * the launch stream.  Returns a negative value when unavailable. */

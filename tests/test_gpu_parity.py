@@ -436,6 +436,35 @@ def test_cli_main_config1_on_nifti_files(t2, tmp_path, monkeypatch):
     assert abs(csv["meanT2"][3] - gt[3]) < 0.1 * gt[3]
 
 
+def test_label_stats_match_numpy_nanmean_nanstd(t2):
+    """t2fit_label_stats_dev against the loop it replaces (utils/t2map_utils.py:43-53): np.nanmean / np.nanstd
+    per label, to 1e-12 relative (summation order differs), exact zeros for constant regions, NaN for empty
+    labels, NaN values skipped, labels outside 1..n ignored, result identical from run to run."""
+    rng = np.random.default_rng(5)
+    for shape, n_lab in (((20, 64, 64), 14), ((3, 7, 11), 3), ((1, 1, 5), 2), ((40, 100, 130), 32)):
+        m = (rng.normal(150.0, 30.0, size=shape)).astype(np.float32)
+        lab = rng.integers(-1, n_lab + 3, size=shape).astype(np.int16)
+        lab[lab == 2] = 0  # label 2 stays empty
+        m[rng.random(shape) < 0.01] = np.nan
+        if n_lab >= 3:
+            m[lab == 3] = 600.0  # constant region: std exactly 0
+        mean, std, cnt = t2.label_stats(m, lab, n_lab)
+        again = t2.label_stats(m, lab, n_lab)
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip((mean, std, cnt), again))
+        for i in range(n_lab):
+            sel = m[lab == i + 1]
+            assert cnt[i] == np.sum(~np.isnan(sel))
+            if cnt[i] == 0:
+                assert np.isnan(mean[i]) and np.isnan(std[i])
+            else:
+                assert np.isclose(mean[i], np.nanmean(sel.astype(np.float64)), rtol=1e-12)
+                assert np.isclose(std[i], np.nanstd(sel.astype(np.float64)), rtol=1e-9, atol=1e-12)
+        if n_lab >= 3 and cnt[2] > 0:
+            assert std[2] == 0.0 and mean[2] == 600.0
+    with pytest.raises(Exception):
+        t2.label_stats(m, lab, 33)
+
+
 def test_streamed_subjects_equal_per_subject_fits(t2):
     """Config 5 path: double-buffered host->HBM streaming of several subjects == one fit per subject."""
     from fetal_t2mapping_amd import stream, synth
