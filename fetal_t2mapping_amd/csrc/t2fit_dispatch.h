@@ -25,6 +25,9 @@ inline LaneParams make_lane_params(const t2fit_config& c) {
   for (int j = 0; j < 3; ++j) { P.x0[j] = c.x0[j]; P.lb[j] = c.lb[j]; P.ub[j] = c.ub[j]; }
   P.ftol = c.ftol; P.gtol = c.gtol; P.fd_step = c.fd_step; P.lm_xtol = c.lm_xtol;
   P.np_k_ub = c.noprior_k_ub; P.np_t2_lb = c.noprior_t2_lb; P.np_t2_ub = c.noprior_t2_ub;
+  P.lm_r_lo = 1.0 / (c.no_prior ? c.noprior_t2_ub : c.ub[1]);
+  P.lm_r_hi = 1.0 / (c.no_prior ? c.noprior_t2_lb : c.lb[1]);
+  P.lm_r_x0 = 1.0 / c.x0[1];
   return P;
 }
 

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void fit_persistent_kernel(const LaneParams
   const EchoView y{col, kLdsStride};
   int q_head = 0, q_count = 0;
   bool chunks_left = true;
-  bool busy = false;
+  bool busy = false, done = false;
   int64_t v = 0;
   typename A::Solver s;
   ObjCtx c;
@@ -330,6 +330,14 @@ __global__ __launch_bounds__(kBlock) void fit_persistent_kernel(const LaneParams
     // active, so it is entered when at least refill_min lanes are idle (or nothing is running).
     const unsigned long long need = __ballot(!busy);
     if (__popcll(need) >= refill_min || need == ~0ull) {
+      // lanes that finished since the last refill hand in their results here, together, rather than one
+      // or two at a time in the round they finished (the conversion and the stores are divergent code)
+      if (done) {
+        LaneResult r;
+        A::result(s, c, r);
+        store_fit(m, v, r);
+        done = false;
+      }
       const int n_need = __popcll(need);
       while (q_count < n_need && chunks_left) {
         unsigned long long cidx = 0;
@@ -441,15 +449,16 @@ __global__ __launch_bounds__(kBlock) void fit_persistent_kernel(const LaneParams
     }
     if (busy) s.eval(c);
     T2_STAMP(st_eval)
-    if (busy) {
-      if (s.advance(c)) {
-        LaneResult r;
-        A::result(s, c, r);
-        store_fit(m, v, r);
-        busy = false;
-      }
+    if (busy && s.advance(c)) {
+      busy = false;
+      done = true;
     }
     T2_STAMP(st_adv)
+  }
+  if (done) {  // (every exit passes through the refill block above; kept for safety)
+    LaneResult r;
+    A::result(s, c, r);
+    store_fit(m, v, r);
   }
 #if defined(T2_PHASE_STAMPS)
   if (lane == 0) {

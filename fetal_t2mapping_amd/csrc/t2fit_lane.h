@@ -33,6 +33,9 @@ struct LaneParams {
   double x0[3], lb[3], ub[3];
   double ftol, gtol, fd_step, lm_xtol;
   double np_k_ub, np_t2_lb, np_t2_ub;
+  // LM works in R = 1/T2: reciprocals of the T2 box in force (table or no-prior) and of the start point,
+  // formed once on the host instead of by three float64 divisions per voxel
+  double lm_r_lo, lm_r_hi, lm_r_x0;
 };
 
 // One voxel's samples: element i lives at p[i*stride].  In the kernels p points into LDS (one

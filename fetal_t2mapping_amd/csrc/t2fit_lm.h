@@ -101,8 +101,10 @@ T2_HD void lm_step(const LmEval<T>& e, T lambda, const bool* fixed, T* d) {
 }
 
 template <typename T> struct LmTol;
-template <> struct LmTol<double> { static constexpr double xtol = 1e-6, ftiny = 1e-12; };
-template <> struct LmTol<float> { static constexpr float xtol = 1e-5f, ftiny = 1e-6f; };
+// xtol: relative step; ftiny: relative objective decrease (actual, or predicted by the damped model) below
+// which the fit has converged; fnoise: how far rounding can push the objective of a trial point up
+template <> struct LmTol<double> { static constexpr double xtol = 1e-6, ftiny = 1e-12, fnoise = 1e-13; };
+template <> struct LmTol<float> { static constexpr float xtol = 1e-5f, ftiny = 1e-6f, fnoise = 4e-6f; };
 
 // Weighted log-linear regression ln y = ln k - R t with weights y^2 (matches the least-squares
 // objective to first order).  Returns false if fewer than two positive samples.
@@ -154,10 +156,10 @@ struct LmLane {
     for (int j = 0; j < 3; ++j) { lbd[j] = lb_[j]; ubd[j] = ub_[j]; }
     lo[0] = NP == 3 ? (T)sq(lbd[0]) : (T)lbd[0];
     hi[0] = NP == 3 ? (T)sq(ubd[0]) : (T)ubd[0];
-    lo[1] = (T)(1.0 / ubd[1]); hi[1] = (T)(1.0 / lbd[1]);  // R = 1/T2 reverses the interval
+    lo[1] = (T)P.lm_r_lo; hi[1] = (T)P.lm_r_hi;  // R = 1/T2 reverses the interval: 1/ub, 1/lb (make_lane_params)
     lo[2] = (T)sq(lbd[2]); hi[2] = (T)sq(ubd[2]);
     qn[0] = t2_clip(NP == 3 ? (T)sq(x0[0]) : (T)x0[0], lo[0], hi[0]);
-    qn[1] = t2_clip((T)(1.0 / x0[1]), lo[1], hi[1]);
+    qn[1] = t2_clip((T)P.lm_r_x0, lo[1], hi[1]);
     qn[2] = (NP == 3) ? t2_clip((T)sq(x0[2]), lo[2], hi[2]) : T(0);
     for (int j = 0; j < 3; ++j) x0q[j] = qn[j];
     stage = 0;
@@ -242,6 +244,14 @@ struct LmLane {
         }
         if (rel <= xtol || act <= (T)LmTol<T>::ftiny * e.f) { status = T2FIT_ST_CONVERGED; ++it; return true; }
       } else {
+        // rejected.  If the damped model itself promised less than the objective can resolve in T, the
+        // rejection is rounding noise and no damping will do better (MINPACK's actred/prered test): stop
+        // here instead of walking lambda up through a dozen more evaluations.
+        if (t2_finite(en.f) && pred <= (T)LmTol<T>::ftiny * e.f && -act <= (T)LmTol<T>::fnoise * e.f) {
+          status = T2FIT_ST_CONVERGED;
+          ++it;
+          return true;
+        }
         lambda *= nu;
         nu *= T(2);
         if (lambda > T(1e14)) { status = T2FIT_ST_CONVERGED; return true; }  // no descent left at any damping
@@ -273,10 +283,11 @@ struct LmLane {
 
   T2_HD void result(const ObjCtx& c, LaneResult& out) const {
     // back to (k, T2, sigma); a coordinate sitting on a bound is snapped onto it exactly
-    out.x[0] = NP == 3 ? (q[0] <= lo[0] && lbd[0] > 0.0 ? lbd[0] : (q[0] >= hi[0] ? ubd[0] : sqrt((double)q[0])))
+    // (square root and reciprocal in the solver's own precision: the iterate carries no more than that)
+    out.x[0] = NP == 3 ? (q[0] <= lo[0] && lbd[0] > 0.0 ? lbd[0] : (q[0] >= hi[0] ? ubd[0] : (double)t2_sqrt(q[0])))
                        : (double)q[0];
-    out.x[1] = q[1] <= lo[1] ? ubd[1] : (q[1] >= hi[1] ? lbd[1] : 1.0 / (double)q[1]);
-    out.x[2] = (NP == 3) ? (q[2] <= lo[2] && lbd[2] > 0.0 ? lbd[2] : (q[2] >= hi[2] ? ubd[2] : sqrt((double)q[2]))) : 0.0;
+    out.x[1] = q[1] <= lo[1] ? ubd[1] : (q[1] >= hi[1] ? lbd[1] : (double)(T(1) / q[1]));
+    out.x[2] = (NP == 3) ? (q[2] <= lo[2] && lbd[2] > 0.0 ? lbd[2] : (q[2] >= hi[2] ? ubd[2] : (double)t2_sqrt(q[2]))) : 0.0;
     out.fun = (double)e.f / c.P->n_te;
     out.nit = it;
     out.nfev = it + 1;
