@@ -287,7 +287,7 @@ template <typename T, int NPAR> struct LmLaneAdaptor {
   using Solver = LmLane<T, NPAR>;
   static constexpr int NP = NPAR;
   static constexpr int kHistDoubles = 0;
-  static constexpr int kRefillMin = 16;  // measured (f32, 3 parameters): 1 -> 2.36 ms, 16 -> 1.92 ms, 32 -> 1.98 ms
+  static constexpr int kRefillMin = 24;  // measured (f32, 3 parameters, MI355X): 8 -> 1.62 ms, 16 -> 1.42 ms, 24 -> 1.35 ms, 32 -> 1.35 ms
   __device__ static void init(Solver& s, const ObjCtx& c, const double* x0, const double* lb, const double* ub,
                               double*) { s.init(c, x0, lb, ub); }
   __device__ static void result(const Solver& s, const ObjCtx& c, LaneResult& r) { s.result(c, r); }

@@ -91,3 +91,31 @@ def fit_volume_sharded(echoes: np.ndarray, mask: Optional[np.ndarray], TEeffs, f
                                C.byref(maps), C.c_void_p(st)))
     full = gather_maps(packed, n, group)
     return T2Maps(*(full[j].reshape(spatial) for j in range(N_MAPS)))
+
+
+def subjects_of_rank(n_subjects: int, rank: int, world: int) -> range:
+    """BASELINE.json config 5 (32 subjects over 8 GPUs): subject s belongs to rank ``s % world``.  Whole
+    subjects are independent, so nothing is exchanged: every rank streams its own subjects host->HBM->host
+    (``stream.fit_subjects``) and writes its own output files."""
+    if not 0 <= rank < world:
+        raise ValueError("rank outside [0, world)")
+    return range(rank, n_subjects, world)
+
+
+def fit_subjects_round_robin(load_subject, n_subjects: int, TEeffs, fit, fit_params, prior=True, norm=False, *,
+                             rank: Optional[int] = None, world: Optional[int] = None, **stream_kw):
+    """Yield ``(s, T2Maps)`` for the subjects of this rank, streamed double-buffered through this rank's GPU.
+
+    ``load_subject(s) -> (echoes (nTE,Z,Y,X), mask or None)`` is called lazily, one subject ahead of the
+    fit (e.g. ``nifti.read_stack`` into pinned memory).  ``rank`` / ``world`` default to the initialised
+    ``torch.distributed`` group, or to a single process."""
+    from . import stream
+
+    if rank is None or world is None:
+        import torch.distributed as dist
+
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    mine = subjects_of_rank(n_subjects, rank, world)
+    fitted = stream.fit_subjects((load_subject(s) for s in mine), TEeffs, fit, fit_params, prior, norm, **stream_kw)
+    for s, maps in zip(mine, fitted):
+        yield s, maps

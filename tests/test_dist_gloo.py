@@ -69,3 +69,30 @@ def test_slab_ranges_cover_the_volume():
             assert all(hi - lo <= per for lo, hi in spans)
     # cfg4: 360 slices over 8 GPUs are whole Z-slabs of 45 slices
     assert t2dist.slab_range(360 * 512 * 512, 3, 8) == (3 * 45 * 512 * 512, 4 * 45 * 512 * 512)
+
+
+def test_subject_round_robin_covers_every_subject_once(monkeypatch):
+    """Config 5 (32 subjects over 8 GPUs): subject s goes to rank s % world; every subject is fitted exactly
+    once, in order within a rank, and the loader is called lazily.  The streaming fit is replaced by a stand-in."""
+    from fetal_t2mapping_amd import stream
+
+    for n, world in ((32, 8), (5, 4), (3, 8), (0, 2)):
+        seen = sorted(s for r in range(world) for s in t2dist.subjects_of_rank(n, r, world))
+        assert seen == list(range(n))
+    assert list(t2dist.subjects_of_rank(32, 3, 8)) == [3, 11, 19, 27]
+    with pytest.raises(ValueError):
+        t2dist.subjects_of_rank(4, 2, 2)
+    loaded = []
+
+    def fake_stream(subjects, TEeffs, fit, fit_params, prior, norm, **kw):
+        for e, m in subjects:
+            yield float(e.sum())
+
+    monkeypatch.setattr(stream, "fit_subjects", fake_stream)
+
+    def load(s):
+        loaded.append(s)
+        return np.full((2, 1, 1, 1), s, np.float32), None
+
+    got = list(t2dist.fit_subjects_round_robin(load, 10, [1.0, 2.0], "gaussian", {}, rank=1, world=4))
+    assert got == [(1, 2.0), (5, 10.0), (9, 18.0)] and loaded == [1, 5, 9]

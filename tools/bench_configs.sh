@@ -3,6 +3,7 @@ run() { python bench.py "$@" --steps 5 --warmup 1 --cpu-seconds 0 --no-also 2>/d
 run --shape 20 64 64 --n-te 6 --fit gaussian --no-prior                  # cfg1 phantom size
 run --shape 180 256 256 --n-te 6 --fit gaussian                          # cfg2 (2-parameter)
 run --shape 180 256 256 --n-te 6 --fit gaussian --solver lm --precision f32
+run --shape 180 256 256 --n-te 6 --fit gaussian --solver loglin          # cfg2 as BASELINE.json words it: log-linear closed form
 run --shape 180 256 256 --n-te 6 --fit gaussian_rician                   # cfg3 (3-parameter)
 run --shape 180 256 256 --n-te 6 --fit gaussian_rician --solver lm --precision f32
 run --shape 180 256 256 --n-te 6 --fit rician                            # Rician likelihood model
