@@ -36,6 +36,10 @@ struct LaneParams {
   // LM works in R = 1/T2: reciprocals of the T2 box in force (table or no-prior) and of the start point,
   // formed once on the host instead of by three float64 divisions per voxel
   double lm_r_lo, lm_r_hi, lm_r_x0;
+  // Taylor coefficients 1/11! .. 1/2! of t2_exp_res(), read from the kernel-argument segment into scalar
+  // registers: as literals the compiler re-materialises each one with two v_mov per use (a third of the
+  // vector instructions of the residual pass)
+  double exp_c[10];
 };
 
 // One voxel's samples: element i lives at p[i*stride].  In the kernels p points into LDS (one
@@ -186,24 +190,23 @@ T2_HD bool lane_bounds(const LaneParams& P, float y0_raw, double* lb, double* ub
 // 2^n.  A few ulp of float64 instead of the library's < 1 ulp at about a third of its instructions; the
 // float32 rounding of the prediction flips for about one sample in 10^7.  NaN propagates; arguments
 // below -746 (including -inf) give 0.  Not used inside any solver.
-T2_HD double t2_exp_res(double x) {
+T2_HD double t2_exp_res(double x, const double* cc) {
   const double n = nearbyint(x * 1.4426950408889634);
   double r = fma(n, -6.93147180369123816490e-01, x);
   r = fma(n, -1.90821492927058770002e-10, r);
-  double p = 2.50521083854417187751e-08;           // 1/11!
-  p = fma(p, r, 2.75573192239858906526e-07);       // 1/10!
-  p = fma(p, r, 2.75573192239858906526e-06);       // 1/9!
-  p = fma(p, r, 2.48015873015873015873e-05);       // 1/8!
-  p = fma(p, r, 1.98412698412698412698e-04);       // 1/7!
-  p = fma(p, r, 1.38888888888888888889e-03);       // 1/6!
-  p = fma(p, r, 8.33333333333333333333e-03);       // 1/5!
-  p = fma(p, r, 4.16666666666666666667e-02);       // 1/4!
-  p = fma(p, r, 1.66666666666666666667e-01);       // 1/3!
-  p = fma(p, r, 0.5);
+  double p = cc[0];
+#if defined(T2_DEVICE_COMPILE)
+#pragma unroll
+#endif
+  for (int j = 1; j < 10; ++j) p = fma(p, r, cc[j]);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
-  const double nc = n < -2000.0 ? -2000.0 : (n > 2000.0 ? 2000.0 : n);  // keeps the int conversion defined
+  const double nc = fmin(fmax(n, -2000.0), 2000.0);  // keeps the int conversion defined (NaN -> -2000, p is NaN then)
   return x < -746.0 ? 0.0 : ldexp(p, (int)nc);  // exp(-inf) = 0 (a T2 of 0 ms handed to the residual entry point)
+}
+inline void t2_exp_res_coefficients(double* cc) {  // 1/11!, 1/10!, ..., 1/2!
+  double f = 1.0;
+  for (int j = 2; j <= 11; ++j) { f *= j; cc[11 - j] = 1.0 / f; }
 }
 
 // a / b from r = 1/b (correctly rounded) with one residual correction: the correctly rounded quotient
@@ -224,30 +227,24 @@ T2_HD float residual_mean(const ObjCtx& c, float k32, float t232, float s32) {
   auto resid = [&](int i) {
     const double te = c.P->te[i];
     double pred;
-    if (gauss) pred = k * t2_exp_res(t2_div_by_rcp(-te, t2, rt2));
-    else pred = t2_sqrt(k2 * t2_exp_res(t2_div_by_rcp(-2.0 * te, t2, rt2)) + s2);
+    if (gauss) pred = k * t2_exp_res(t2_div_by_rcp(-te, t2, rt2), c.P->exp_c);
+    else pred = t2_sqrt(k2 * t2_exp_res(t2_div_by_rcp(-2.0 * te, t2, rt2), c.P->exp_c) + s2);
     return c.sample(i) - (float)pred;
   };
   // numpy float32 add.reduce over a contiguous row: n < 8 sequential from 0; otherwise eight
   // interleaved partial sums over the first n - n%8 items, combined as a balanced tree, then the
   // remaining items added one by one.
-  if (n <= 8) {  // the usual echo-train lengths: straight-line code, the eight exp() chains interleave
+  if (n == 8) {  // branch-free block: the eight exp() chains interleave and share their constants
     float r[8];
 #if defined(T2_DEVICE_COMPILE)
 #pragma unroll
 #endif
-    for (int i = 0; i < 8; ++i) r[i] = i < n ? resid(i) : 0.0f;
-    float sum;
-    if (n == 8) {
-      sum = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    } else {
-      sum = 0.0f;
-#if defined(T2_DEVICE_COMPILE)
-#pragma unroll
-#endif
-      for (int i = 0; i < 7; ++i)
-        if (i < n) sum += r[i];
-    }
+    for (int i = 0; i < 8; ++i) r[i] = resid(i);
+    return (((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))) / 8.0f;
+  }
+  if (n < 8) {  // sequential sum from 0, as numpy does below eight items
+    float sum = 0.0f;
+    for (int i = 0; i < n; ++i) sum += resid(i);
     return sum / (float)n;
   }
   // longer trains: r8 is indexed through selects so it stays in registers
