@@ -117,17 +117,17 @@ T2_HD double t2_max3(double a, double b, double c) { return t2_max(a, t2_max(b, 
 // 3*(fy-fp)/(stp-sty) are the same floating-point number).
 T2_HD void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy, double& dy, double& stp,
                   double fp, double dp, bool& brackt, double stpmin, double stpmax) {
-  const double sgnd = dp * (dx / t2_abs(dx));
+  const double sgnd = !(dx < 0.0 || dx > 0.0) ? (double)NAN : (dx < 0.0 ? -dp : dp);  // dp * (dx / |dx|): the factor is exactly +-1
   const bool c1 = fp > fx;                              // higher function value: minimum bracketed
   const bool c2 = !c1 && sgnd < 0.0;                    // derivatives of opposite sign: bracketed
   const bool c3 = !c1 && !c2 && t2_abs(dp) < t2_abs(dx);  // derivative magnitude decreases
   const bool c4 = !c1 && !c2 && !c3;                    // derivative does not decrease
   // cubic through (sta, fa, da) and (stp, fp, dp): a = y in case 4, a = x otherwise
   const double sta = c4 ? sty : stx, fa = c4 ? fy : fx, da = c4 ? dy : dx;
-  const double theta = 3.0 * (fa - fp) / (stp - sta) + da + dp;
+  const double theta = t2_fdiv(3.0 * (fa - fp), stp - sta) + da + dp;
   const double s = t2_max3(t2_abs(theta), t2_abs(da), t2_abs(dp));
-  const double ts = theta / s;
-  double arg = ts * ts - (da / s) * (dp / s);
+  const double ts = t2_fdiv(theta, s);
+  double arg = ts * ts - t2_fdiv(da, s) * t2_fdiv(dp, s);
   if (c3) arg = t2_max(0.0, arg);
   double gamma = s * t2_sqrt(arg);
   const bool flip = c1 ? stp < stx : (c4 ? stp > sty : stp > stx);
@@ -135,12 +135,12 @@ T2_HD void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy, 
   const double gd1 = c1 ? dx : dp;  // the slope subtracted from gamma
   const double p = (gamma - gd1) + theta;
   const double q = c3 ? (gamma + (dx - dp)) + gamma : ((gamma - gd1) + gamma) + (c1 ? dp : (c2 ? dx : dy));
-  const double r = p / q;
+  const double r = t2_fdiv(p, q);
   // cubic step
   double stpc = c1 ? stx + r * (stp - stx) : stp + r * (sta - stp);
   if (c3 && !(r < 0.0 && gamma != 0.0)) stpc = stp > stx ? stpmax : stpmin;
   // quadratic (case 1) or secant (cases 2, 3) step
-  const double quad = c1 ? dx / ((fx - fp) / (stp - stx) + dx) / 2.0 : dp / (dp - dx);
+  const double quad = c1 ? t2_fdiv(dx, t2_fdiv(fx - fp, stp - stx) + dx) * 0.5 : t2_fdiv(dp, dp - dx);
   const double stpq = c1 ? stx + quad * (stp - stx) : stp + quad * (stx - stp);
   double stpf;
   if (c1) {
@@ -498,8 +498,11 @@ struct Lbfgsb {
       if (iwhere[i] == 0) {
         d[i] = neggi;
         f1 -= neggi * neggi;
-        if (neggi < 0.0) { tbk[i] = tl / (-neggi); hasbk[i] = true; ++nbreak; }
-        else if (neggi > 0.0) { tbk[i] = tu / neggi; hasbk[i] = true; ++nbreak; }
+        if (neggi != 0.0) {  // one division on the selected numerator instead of one per branch
+          tbk[i] = t2_fdiv(neggi < 0.0 ? tl : tu, t2_abs(neggi));
+          hasbk[i] = true;
+          ++nbreak;
+        }
       }
     }
     if (nbreak == 0) return;  // every moving variable is box-bounded here, so d == 0
@@ -513,7 +516,7 @@ struct Lbfgsb {
       return s;
     };
     double f2 = dBd(d);
-    double dtm = -f1 / f2;
+    double dtm = t2_fdiv(-f1, f2);
     double tsum = 0.0, tj = 0.0;
     int nleft = nbreak;
     bool all_fixed = false;
@@ -564,7 +567,7 @@ struct Lbfgsb {
         f1 += d[i] * (g[i] + bz);
       }
       f2 = t2_max(epsmch * f2_org, dBd(d));
-      if (nleft > 0) dtm = -f1 / f2;
+      if (nleft > 0) dtm = t2_fdiv(-f1, f2);
       else { f1 = 0.0; f2 = 0.0; dtm = 0.0; }  // all remaining variables are box-bounded
     }
     if (all_fixed) return;
@@ -601,14 +604,14 @@ struct Lbfgsb {
     if (N == 2) rr[2] = 0.0;
     const double d0 = A[0][0];
     if (!(d0 > 0.0)) return false;
-    const double l10 = A[1][0] / d0, l20 = A[2][0] / d0;
+    const double l10 = t2_fdiv(A[1][0], d0), l20 = t2_fdiv(A[2][0], d0);
     const double d1 = A[1][1] - l10 * A[1][0];
     if (!(d1 > 0.0)) return false;
-    const double l21 = (A[2][1] - l20 * A[1][0]) / d1;
+    const double l21 = t2_fdiv(A[2][1] - l20 * A[1][0], d1);
     const double d2 = A[2][2] - l20 * A[2][0] - l21 * (A[2][1] - l20 * A[1][0]);
     if (!(d2 > 0.0)) return false;
     const double y0 = rr[0], y1 = rr[1] - l10 * y0, y2 = rr[2] - l20 * y0 - l21 * y1;
-    const double u2 = y2 / d2, u1 = y1 / d1 - l21 * u2, u0 = y0 / d0 - l10 * u1 - l20 * u2;
+    const double u2 = t2_fdiv(y2, d2), u1 = t2_fdiv(y1, d1) - l21 * u2, u0 = t2_fdiv(y0, d0) - l10 * u1 - l20 * u2;
     du[0] = u0; du[1] = u1;
     if (N == 3) du[N - 1] = u2;
     // projected Newton point
@@ -748,7 +751,7 @@ struct Lbfgsb {
             T2_UNROLL
             for (int i = 0; i < N; ++i) { hs(col, i) = d[i]; hy(col, i) = r[i]; }
             ++col;
-            theta = rr / dr;
+            theta = t2_fdiv(rr, dr);
           }
           next = GO_BEGIN;
         }
@@ -793,14 +796,12 @@ struct Lbfgsb {
         T2_UNROLL
         for (int i = 0; i < N; ++i) {
           const double a1 = d[i];
-          if (a1 < 0.0) {
-            const double a2 = lb[i] - x[i];
-            if (a2 >= 0.0) stpmx = 0.0;
-            else if (a1 * stpmx < a2) stpmx = a2 / a1;
-          } else if (a1 > 0.0) {
-            const double a2 = ub[i] - x[i];
-            if (a2 <= 0.0) stpmx = 0.0;
-            else if (a1 * stpmx > a2) stpmx = a2 / a1;
+          if (a1 != 0.0) {  // lower bound limits a decreasing variable, upper bound an increasing one
+            const double a2 = (a1 < 0.0 ? lb[i] : ub[i]) - x[i];
+            const bool at_bound = a1 < 0.0 ? a2 >= 0.0 : a2 <= 0.0;
+            const bool limits = a1 < 0.0 ? a1 * stpmx < a2 : a1 * stpmx > a2;
+            if (at_bound) stpmx = 0.0;
+            else if (limits) stpmx = t2_fdiv(a2, a1);
           }
         }
       }
