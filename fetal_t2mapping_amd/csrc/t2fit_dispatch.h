@@ -29,6 +29,7 @@ inline LaneParams make_lane_params(const t2fit_config& c) {
   P.lm_r_hi = 1.0 / (c.no_prior ? c.noprior_t2_lb : c.lb[1]);
   P.lm_r_x0 = 1.0 / c.x0[1];
   t2_exp_res_coefficients(P.exp_c);
+  P.inv_n = 1.0 / c.n_te;
   return P;
 }
 

@@ -40,6 +40,7 @@ struct LaneParams {
   // registers: as literals the compiler re-materialises each one with two v_mov per use (a third of the
   // vector instructions of the residual pass)
   double exp_c[10];
+  double inv_n;  // 1 / nTE (the objectives are means over the echoes)
 };
 
 // One voxel's samples: element i lives at p[i*stride].  In the kernels p points into LDS (one
@@ -95,8 +96,10 @@ T2_HD double t2_fdiv(double a, double b) {
   const double q = a * r;
   return fma(fma(-q, b, a), r, q);
 }
+T2_HD double t2_rcp_for_div(double b) { return t2_fast_rcp(b); }  // r for t2_div_by_rcp(a, b, r) below
 #else
 T2_HD double t2_fdiv(double a, double b) { return a / b; }
+T2_HD double t2_rcp_for_div(double b) { return 1.0 / b; }
 #endif
 T2_HD double t2_rsqrt(double x) { return 1.0 / sqrt(x); }
 T2_HD double t2_rcp(double x) { return 1.0 / x; }

@@ -342,9 +342,11 @@ struct Lbfgsb {
     // LDS / scalar loads of all samples and echo times can be issued up front, the summation
     // order needs no dispatch); echoes 8..15, if any, in a short run-time loop.
     NpSum s0, s1, s2, s3;
+    const double nd = (double)n, inv_n = P.inv_n;
+    auto mean = [&](double sum) { return t2_div_by_rcp(sum, nd, inv_n); };  // sum / n
     if constexpr (MODEL == T2FIT_MODEL_GAUSSIAN) {
       const double k = x[0], t2 = x[1], kp = x1[0], t2p = x1[1];
-      const double rt2 = 1.0 / t2, rt2p = 1.0 / t2p;  // one IEEE division per T2, shared by every echo
+      const double rt2 = t2_rcp_for_div(t2), rt2p = t2_rcp_for_div(t2p);  // one reciprocal per T2, shared by every echo
       auto body = [&](int i, auto add) {
         const double y = (double)c.sample(i), te = P.te[i];
         const double E = t2_exp(t2_div_by_rcp(-te, t2, rt2)), Ep = t2_exp(t2_div_by_rcp(-te, t2p, rt2p));
@@ -356,13 +358,13 @@ struct Lbfgsb {
         if (J < n) body(J, [&](double a, double b2, double c2, double) { s0.add<J>(a); s1.add<J>(b2); s2.add<J>(c2); });
       });
       for (int i = 8; i < n; ++i) body(i, [&](double a, double b2, double c2, double) { s0.tail(a); s1.tail(b2); s2.tail(c2); });
-      f = s0.total(n) / n;
-      g[0] = (s1.total(n) / n - f) / dx[0];
-      g[1] = (s2.total(n) / n - f) / dx[1];
+      f = mean(s0.total(n));
+      g[0] = t2_fdiv(mean(s1.total(n)) - f, dx[0]);
+      g[1] = t2_fdiv(mean(s2.total(n)) - f, dx[1]);
     } else if constexpr (MODEL == T2FIT_MODEL_GAUSSIAN_RICIAN) {
       const double k2 = x[0] * x[0], kp2 = x1[0] * x1[0], t2 = x[1], t2p = x1[1];
       const double sg2 = x[N - 1] * x[N - 1], sgp2 = x1[N - 1] * x1[N - 1];
-      const double rt2 = 1.0 / t2, rt2p = 1.0 / t2p;
+      const double rt2 = t2_rcp_for_div(t2), rt2p = t2_rcp_for_div(t2p);
       auto body = [&](int i, auto add) {
         const double y = (double)c.sample(i), te = P.te[i];
         const double E = t2_exp(t2_div_by_rcp(-2.0 * te, t2, rt2)), Ep = t2_exp(t2_div_by_rcp(-2.0 * te, t2p, rt2p));
@@ -375,15 +377,15 @@ struct Lbfgsb {
         if (J < n) body(J, [&](double a, double b2, double c2, double d2) { s0.add<J>(a); s1.add<J>(b2); s2.add<J>(c2); s3.add<J>(d2); });
       });
       for (int i = 8; i < n; ++i) body(i, [&](double a, double b2, double c2, double d2) { s0.tail(a); s1.tail(b2); s2.tail(c2); s3.tail(d2); });
-      f = s0.total(n) / n;
-      g[0] = (s1.total(n) / n - f) / dx[0];
-      g[1] = (s2.total(n) / n - f) / dx[1];
-      g[N - 1] = (s3.total(n) / n - f) / dx[N - 1];
+      f = mean(s0.total(n));
+      g[0] = t2_fdiv(mean(s1.total(n)) - f, dx[0]);
+      g[1] = t2_fdiv(mean(s2.total(n)) - f, dx[1]);
+      g[N - 1] = t2_fdiv(mean(s3.total(n)) - f, dx[N - 1]);
     } else {
       const double k = x[0], kp = x1[0], t2 = x[1], t2p = x1[1];
       const double sg2 = x[N - 1] * x[N - 1], sgp2 = x1[N - 1] * x1[N - 1];
       const double ls2 = t2_log(sg2), lsp2 = t2_log(sgp2);
-      const double rt2 = 1.0 / t2, rt2p = 1.0 / t2p;
+      const double rt2 = t2_rcp_for_div(t2), rt2p = t2_rcp_for_div(t2p);
       auto term = [](double kk, double E, double s2v, double ls2v, float yf) {
         const double m = kk * E;
         const double xx = (m * (double)yf) / s2v;
@@ -404,9 +406,9 @@ struct Lbfgsb {
       });
       for (int i = 8; i < n; ++i) body(i, [&](double a, double b2, double c2, double d2) { s0.tail(a); s1.tail(b2); s2.tail(c2); s3.tail(d2); });
       f = -s0.total(n);
-      g[0] = (-s1.total(n) - f) / dx[0];
-      g[1] = (-s2.total(n) - f) / dx[1];
-      g[N - 1] = (-s3.total(n) - f) / dx[N - 1];
+      g[0] = t2_fdiv(-s1.total(n) - f, dx[0]);
+      g[1] = t2_fdiv(-s2.total(n) - f, dx[1]);
+      g[N - 1] = t2_fdiv(-s3.total(n) - f, dx[N - 1]);
     }
   }
 
