@@ -105,6 +105,46 @@ T2_HD double t2_rsqrt(double x) { return 1.0 / sqrt(x); }
 T2_HD double t2_rcp(double x) { return 1.0 / x; }
 T2_HD float t2_sqrt(float x) { return sqrtf(x); }
 
+// exp() and sqrt() of the objective evaluations, device side: the device library's own float64 sequences
+// (same constants, same operations, same order: bit-identical results) without their range handling.
+// exp: arguments here are -te/T2 or -2te/T2 with T2 >= the lower bound, i.e. in (-1075, 0]: the
+// overflow / underflow selects (two compares, four selects per call) are dead code.  sqrt: arguments are
+// k^2 E + sigma^2 in [0, 1e10]: the 2^-767 rescaling never triggers; zero is kept exact by one select.
+#if defined(__HIP_DEVICE_COMPILE__)
+T2_HD double t2_exp_core(double x) {
+  const double n = __builtin_rint(x * 0x1.71547652b82fep+0);
+  double r = fma(-0x1.62e42fefa39efp-1, n, x);
+  r = fma(-0x1.abc9e3b39803fp-56, n, r);
+  double p = fma(0x1.ade156a5dcb37p-26, r, 0x1.28af3fca7ab0cp-22);
+  p = fma(r, p, 0x1.71dee623fde64p-19);
+  p = fma(r, p, 0x1.a01997c89e6b0p-16);
+  p = fma(r, p, 0x1.a01a014761f6ep-13);
+  p = fma(r, p, 0x1.6c16c1852b7b0p-10);
+  p = fma(r, p, 0x1.1111111122322p-7);
+  p = fma(r, p, 0x1.55555555502a1p-5);
+  p = fma(r, p, 0x1.5555555555511p-3);
+  p = fma(r, p, 0x1.000000000000bp-1);
+  p = fma(r, p, 1.0);
+  p = fma(r, p, 1.0);
+  return __builtin_ldexp(p, (int)n);
+}
+T2_HD double t2_sqrt_core(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = y * 0.5;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  double d = fma(-g, g, x);
+  h = fma(h, r, h);
+  g = fma(d, h, g);
+  d = fma(-g, g, x);
+  g = fma(d, h, g);
+  return x == 0.0 ? x : g;
+}
+#else
+T2_HD double t2_exp_core(double x) { return exp(x); }
+T2_HD double t2_sqrt_core(double x) { return sqrt(x); }
+#endif
+
 template <typename T> T2_HD T t2_min(T a, T b) { return a < b ? a : b; }
 template <typename T> T2_HD T t2_max(T a, T b) { return a > b ? a : b; }
 // a NaN bound is ignored (a voxel whose S(TE0) is NaN keeps the table start point, as scipy reports it)

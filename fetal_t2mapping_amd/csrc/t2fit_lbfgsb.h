@@ -349,7 +349,7 @@ struct Lbfgsb {
       const double rt2 = t2_rcp_for_div(t2), rt2p = t2_rcp_for_div(t2p);  // one reciprocal per T2, shared by every echo
       auto body = [&](int i, auto add) {
         const double y = (double)c.sample(i), te = P.te[i];
-        const double E = t2_exp(t2_div_by_rcp(-te, t2, rt2)), Ep = t2_exp(t2_div_by_rcp(-te, t2p, rt2p));
+        const double E = t2_exp_core(t2_div_by_rcp(-te, t2, rt2)), Ep = t2_exp_core(t2_div_by_rcp(-te, t2p, rt2p));
         const double r0 = y - k * E, r1 = y - kp * E, r2 = y - k * Ep;
         add(r0 * r0, r1 * r1, r2 * r2, 0.0);
       };
@@ -367,9 +367,9 @@ struct Lbfgsb {
       const double rt2 = t2_rcp_for_div(t2), rt2p = t2_rcp_for_div(t2p);
       auto body = [&](int i, auto add) {
         const double y = (double)c.sample(i), te = P.te[i];
-        const double E = t2_exp(t2_div_by_rcp(-2.0 * te, t2, rt2)), Ep = t2_exp(t2_div_by_rcp(-2.0 * te, t2p, rt2p));
-        const double r0 = y - t2_sqrt(k2 * E + sg2), r1 = y - t2_sqrt(kp2 * E + sg2);
-        const double r2 = y - t2_sqrt(k2 * Ep + sg2), r3 = y - t2_sqrt(k2 * E + sgp2);
+        const double E = t2_exp_core(t2_div_by_rcp(-2.0 * te, t2, rt2)), Ep = t2_exp_core(t2_div_by_rcp(-2.0 * te, t2p, rt2p));
+        const double r0 = y - t2_sqrt_core(k2 * E + sg2), r1 = y - t2_sqrt_core(kp2 * E + sg2);
+        const double r2 = y - t2_sqrt_core(k2 * Ep + sg2), r3 = y - t2_sqrt_core(k2 * E + sgp2);
         add(r0 * r0, r1 * r1, r2 * r2, r3 * r3);
       };
       static_for<0, 8>([&](auto JC) {
@@ -397,7 +397,7 @@ struct Lbfgsb {
       auto body = [&](int i, auto add) {
         const float yf = c.sample(i);
         const double te = P.te[i];
-        const double E = t2_exp(t2_div_by_rcp(-te, t2, rt2)), Ep = t2_exp(t2_div_by_rcp(-te, t2p, rt2p));
+        const double E = t2_exp_core(t2_div_by_rcp(-te, t2, rt2)), Ep = t2_exp_core(t2_div_by_rcp(-te, t2p, rt2p));
         add(term(k, E, sg2, ls2, yf), term(kp, E, sg2, ls2, yf), term(k, Ep, sg2, ls2, yf), term(k, E, sgp2, lsp2, yf));
       };
       static_for<0, 8>([&](auto JC) {
