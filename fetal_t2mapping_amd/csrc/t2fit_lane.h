@@ -12,6 +12,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/t2fit.h"
 
 #if defined(__HIPCC__)
@@ -41,6 +43,7 @@ struct LaneParams {
   // vector instructions of the residual pass)
   double exp_c[10];
   double inv_n;  // 1 / nTE (the objectives are means over the echoes)
+  double lbfgsb_tol;  // factr * epsmch = (ftol / eps) * eps, the relative-reduction stop of L-BFGS-B
 };
 
 // One voxel's samples: element i lives at p[i*stride].  In the kernels p points into LDS (one
@@ -165,6 +168,14 @@ template <> struct TeOf<double> {
 template <> struct TeOf<float> {
   T2_HD static float at(const LaneParams& P, int i) { return P.te_f[i]; }
 };
+
+// compile-time loop: f(std::integral_constant<int, J>) for J in [J0, JN)
+template <int J, int JN, class F> T2_HD void static_for(F&& f) {
+  if constexpr (J < JN) {
+    f(std::integral_constant<int, J>{});
+    static_for<J + 1, JN>(f);
+  }
+}
 
 // ---- exponentially scaled modified Bessel function I0 (scipy.special.i0e = Cephes i0e) ---------
 // Chebyshev expansions from Cephes i0.c (public domain, Moshier): [0,8] and (8,inf).

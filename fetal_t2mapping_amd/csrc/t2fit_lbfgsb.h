@@ -129,7 +129,7 @@ T2_HD void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy, 
   const double ts = t2_fdiv(theta, s);
   double arg = ts * ts - t2_fdiv(da, s) * t2_fdiv(dp, s);
   if (c3) arg = t2_max(0.0, arg);
-  double gamma = s * t2_sqrt(arg);
+  double gamma = s * t2_sqrt_core(arg);
   const bool flip = c1 ? stp < stx : (c4 ? stp > sty : stp > stx);
   if (flip) gamma = -gamma;
   const double gd1 = c1 ? dx : dp;  // the slope subtracted from gamma
@@ -144,7 +144,7 @@ T2_HD void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy, 
   const double stpq = c1 ? stx + quad * (stp - stx) : stp + quad * (stx - stp);
   double stpf;
   if (c1) {
-    stpf = t2_abs(stpc - stx) < t2_abs(stpq - stx) ? stpc : stpc + (stpq - stpc) / 2.0;
+    stpf = t2_abs(stpc - stx) < t2_abs(stpq - stx) ? stpc : stpc + (stpq - stpc) * 0.5;
   } else if (c2) {
     stpf = t2_abs(stpc - stp) > t2_abs(stpq - stp) ? stpc : stpq;
   } else if (c3) {
@@ -176,12 +176,12 @@ T2_HD void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy, 
 
 // START call of dcsrch: validates the first step and initialises the search state.
 T2_HD void dcsrch_start(double f, double g, double stp, double ftol, double stpmin, double stpmax, LsState& s) {
-  const double xtrapu = 4.0, p5 = 0.5;
+  const double xtrapu = 4.0;
   if (stp < stpmin || stp > stpmax || g >= 0.0) { s.task = LS_ERROR; return; }
   s.brackt = false;
   s.stage = 1;
   s.finit = f; s.ginit = g; s.gtest = ftol * s.ginit;
-  s.width = stpmax - stpmin; s.width1 = s.width / p5;
+  s.width = stpmax - stpmin; s.width1 = s.width * 2.0;  // width / 0.5
   s.stx = 0.0; s.fx = s.finit; s.gx = s.ginit;
   s.sty = 0.0; s.fy = s.finit; s.gy = s.ginit;
   s.stmin = 0.0; s.stmax = stp + xtrapu * stp;
@@ -261,12 +261,6 @@ struct NpSum {
   T2_HD double total(int n) const { return n < 8 ? seq : s; }
 };
 
-template <int J, int JN, class F> T2_HD void static_for(F&& f) {
-  if constexpr (J < JN) {
-    f(std::integral_constant<int, J>{});
-    static_for<J + 1, JN>(f);
-  }
-}
 
 // ---- the solver -----------------------------------------------------------------------------------
 // Resumable (reverse-communication) form, like the library's own driver loop: the caller evaluates
@@ -646,11 +640,11 @@ struct Lbfgsb {
           if (dk < 0.0) {
             const double temp2 = lb[i] - z[i];
             if (temp2 >= 0.0) temp1 = 0.0;
-            else if (dk * alpha < temp2) temp1 = temp2 / dk;
+            else if (dk * alpha < temp2) temp1 = t2_fdiv(temp2, dk);
           } else if (dk > 0.0) {
             const double temp2 = ub[i] - z[i];
             if (temp2 <= 0.0) temp1 = 0.0;
-            else if (dk * alpha > temp2) temp1 = temp2 / dk;
+            else if (dk * alpha > temp2) temp1 = t2_fdiv(temp2, dk);
           }
           if (temp1 < alpha) {
             alpha = temp1;
@@ -726,7 +720,7 @@ struct Lbfgsb {
           tr[0] = x[0]; tr[1] = x[1]; tr[2] = N == 3 ? x[N - 1] : 0.0; tr[3] = f;
         }
         sbgnrm = projgr(x, g);
-        const double tol = (P.ftol / epsmch) * epsmch;  // factr * epsmch
+        const double tol = P.lbfgsb_tol;  // factr * epsmch = (ftol / epsmch) * epsmch, formed on the host
         if (nit >= P.maxiter || nfev > P.maxfun) {
           next = GO_DONE;  // scipy: STOP, success False
         } else if (sbgnrm <= P.gtol || (fold - f) <= tol * t2_max3(t2_abs(fold), t2_abs(f), 1.0)) {

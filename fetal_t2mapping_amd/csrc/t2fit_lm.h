@@ -33,7 +33,7 @@ T2_HD void lm_eval(const ObjCtx& c, const T* q, LmEval<T>& e) {
   const int n = P.n_te;
   const T k = q[0], R = q[1], s = (NP == 3) ? q[2] : T(0);
   T f = 0, akk = 0, akr = 0, aks = 0, arr = 0, ars = 0, ass = 0, gk = 0, gr = 0, gs = 0;
-  for (int i = 0; i < n; ++i) {
+  auto echo = [&](int i) {
     const T t = TeOf<T>::at(P, i);
     const T y = (T)c.sample(i);
     T jk, jr, js = 0, m;
@@ -64,7 +64,14 @@ T2_HD void lm_eval(const ObjCtx& c, const T* q, LmEval<T>& e) {
       ass += js * js;
       gs += js * r;
     }
-  }
+  };
+  // the first eight echoes with compile-time indices: their echo times (scalar loads) and samples (LDS) are
+  // all requested up front instead of one load-wait pair per loop trip; longer trains continue in a loop
+  static_for<0, 8>([&](auto JC) {
+    constexpr int J = decltype(JC)::value;
+    if (J < n) echo(J);
+  });
+  for (int i = 8; i < n; ++i) echo(i);
   e.f = f;
   e.a[0] = akk; e.a[1] = akr; e.a[2] = aks; e.a[3] = arr; e.a[4] = ars; e.a[5] = ass;
   e.g[0] = gk; e.g[1] = gr; e.g[2] = gs;
