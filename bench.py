@@ -49,6 +49,28 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("T2FIT_BENCH_CORES", "64"))))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
+CLOCK_MHZ, N_SIMD = 2400.0, 256 * 4  # MI355X_MICROARCH.md: 2400 MHz max clock, 256 CUs x 4 SIMD16
+VEC_F64_PEAK_TFLOPS = 256 * 4 * 16 * 2 * 2.4e9 / 1e12  # vector (non-MFMA) float64 FMA peak: 78.6 TFLOP/s
+
+
+def alu_view(key, kernel_ms):
+    """What actually bounds the iterative fits: VALU issue slots.  Instruction counts per launch come from separate
+    rocprofv3 --pmc passes of this same workload (profiles/instr_mix.json, deterministic per launch); the time is live."""
+    path = os.path.join(REPO, "profiles", "instr_mix.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        m = json.load(f).get(key)
+    if not m:
+        return None
+    cycles = kernel_ms * 1e-3 * CLOCK_MHZ * 1e6 * N_SIMD
+    flops = (2 * m.get("valu_fma_f64", 0) + m.get("valu_mul_f64", 0) + m.get("valu_add_f64", 0)
+             + m.get("valu_trans_f64", 0)) * 64 * m["lanes_active"]
+    return {"valu_wave_insts_per_launch": m["valu"], "lanes_active": m["lanes_active"],
+            "valu_issue_utilisation": round(m["valu"] * 4 / cycles, 3),  # >= 4 cycles per wave64 VALU instruction
+            "f64_tflops_active_lanes": round(flops / (kernel_ms * 1e-3) / 1e12, 2),
+            "vector_f64_peak_tflops": round(VEC_F64_PEAK_TFLOPS, 1),
+            "source": "profiles/instr_mix.json (rocprofv3 --pmc SQ_INSTS_VALU*, own passes) / live kernel time"}
 
 
 def parse():
@@ -280,6 +302,9 @@ def main():
                                   "the fit is float64 VALU bound (exp/sqrt/div per objective evaluation), not HBM "
                                   "bound: see DESIGN.md section 6")},
         }
+        alu = alu_view(f"{a.fit}/{a.solver}/{a.precision}/{z}x{y}x{x}x{a.n_te}", k_ms)
+        if alu is not None:
+            out["alu"] = alu
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if also is not None:
