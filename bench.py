@@ -87,6 +87,8 @@ def parse():
     p.add_argument("--no-gather", action="store_true", help="skip the all-gather of the maps (N > 1)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration (0 = skip)")
     p.add_argument("--no-also", action="store_true", help="skip the secondary (converged LM float32) measurement")
+    p.add_argument("--reserve-cus", type=int, default=16,
+                   help="N > 1 with the all-gather: CUs the persistent fit kernel leaves free for RCCL's kernels")
     return p.parse_args()
 
 
@@ -171,6 +173,15 @@ def main():
     do_gather = world > 1 and not a.no_gather
     packed = [torch.empty((4, n_vox), dtype=torch.float32, device=dev) for _ in range(2 if do_gather else 1)]
     gathered = [torch.empty((world, 4, n_vox), dtype=torch.float32, device=dev) for _ in range(2)] if do_gather else None
+    reserved = 0
+    if do_gather and a.solver == "lbfgsb" and a.reserve_cus > 0 and "T2FIT_PERSISTENT_BLOCKS" not in os.environ:
+        # The reference-trajectory kernel is persistent with one workgroup per CU (its LDS-resident history fills the
+        # CU): launched over every CU it leaves RCCL's all-gather kernel nowhere to run until it drains, and the
+        # gather of step i could not overlap the fit of step i+1.  A grid of (CUs - reserve) workgroups keeps a few
+        # CUs free for it.  The library reads the variable once, at its first launch.
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        reserved = min(a.reserve_cus, cus - 1)
+        os.environ["T2FIT_PERSISTENT_BLOCKS"] = str(cus - reserved)
     maps_b = []
     for pk in packed:
         mb = _abi.T2FitMaps()
@@ -292,7 +303,8 @@ def main():
                                    f"{'prior' if not a.no_prior else 'no-prior'} bounds, mask fill {masked / n_vox:.2f}",
                        "solver": a.solver, "fit": a.fit, "n_te": a.n_te, "voxels_per_gpu": n_vox,
                        "masked_voxels_per_gpu": masked,
-                       "parallelism": f"voxel slabs x{world}" + (" + all-gather of 4 maps (overlapped with the next fit)" if do_gather else "")},
+                       "parallelism": f"voxel slabs x{world}" + (" + all-gather of 4 maps (overlapped with the next fit)" if do_gather else ""),
+                       "cus_left_free_for_rccl": reserved},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel": "loglin_volume_kernel" if a.solver == "loglin" else "fit_persistent_kernel",
