@@ -278,6 +278,7 @@ template <int MODEL> struct LbfgsbLane {
   using Solver = Lbfgsb<MODEL>;
   static constexpr int NP = Solver::N;
   static constexpr int kHistDoubles = 2 * Solver::M * Solver::N;  // correction pairs, per lane, in LDS
+  static constexpr int kWavesPerSimd = 1;
   static constexpr int kRefillMin = 8;   // measured on MI355X: 1 -> 28.1 ms, 8 -> 26.8 ms, 16 -> 27.6 ms
   __device__ static void init(Solver& s, const ObjCtx&, const double* x0, const double* lb, const double* ub,
                               double* hist) { s.init(x0, lb, ub, hist, kBlock); }
@@ -287,17 +288,17 @@ template <typename T, int NPAR> struct LmLaneAdaptor {
   using Solver = LmLane<T, NPAR>;
   static constexpr int NP = NPAR;
   static constexpr int kHistDoubles = 0;
+  static constexpr int kWavesPerSimd = sizeof(T) == 4 ? 4 : 1;
   static constexpr int kRefillMin = 24;  // measured (f32, 3 parameters, MI355X): 8 -> 1.62 ms, 16 -> 1.42 ms, 24 -> 1.35 ms, 32 -> 1.35 ms
   __device__ static void init(Solver& s, const ObjCtx& c, const double* x0, const double* lb, const double* ub,
                               double*) { s.init(c, x0, lb, ub); }
   __device__ static void result(const Solver& s, const ObjCtx& c, LaneResult& r) { s.result(c, r); }
 };
 
-template <class A, int kChunk, bool kTrace = false>
-__global__ __launch_bounds__(kBlock) void fit_persistent_kernel(const LaneParams P,
-                                                                       const float* __restrict__ echoes, int layout,
-                                                                       const uint8_t* __restrict__ mask, int64_t n_vox,
-                                                                       DevMaps m, unsigned long long* next_chunk, int refill_min) {
+template <class A, int kChunk, bool kTrace>
+__device__ __forceinline__ void persistent_fit(const LaneParams& P, const float* __restrict__ echoes, int layout,
+                                               const uint8_t* __restrict__ mask, int64_t n_vox, const DevMaps& m,
+                                               unsigned long long* next_chunk, int refill_min) {
   extern __shared__ float lds[];
   constexpr int NP = A::NP;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -469,6 +470,17 @@ __global__ __launch_bounds__(kBlock) void fit_persistent_kernel(const LaneParams
       for (int j = 0; j < 6; ++j) atomicAdd(next_chunk + 4 + j, s.stamp[j]);
   }
 #endif
+}
+
+// The kernel proper.  kWavesPerSimd is the occupancy the register allocator is asked to keep: 1 for the
+// float64 solvers (the L-BFGS-B lane alone holds ~340 registers), 4 for the float32 LM lane, which sits a few
+// registers above the 128-register line of four waves per SIMD without the hint.
+template <class A, int kChunk, bool kTrace = false, int kWavesPerSimd = 1>
+__global__ __launch_bounds__(kBlock, kWavesPerSimd) void fit_persistent_kernel(const LaneParams P,
+                                                                       const float* __restrict__ echoes, int layout,
+                                                                       const uint8_t* __restrict__ mask, int64_t n_vox,
+                                                                       DevMaps m, unsigned long long* next_chunk, int refill_min) {
+  persistent_fit<A, kChunk, kTrace>(P, echoes, layout, mask, n_vox, m, next_chunk, refill_min);
 }
 
 // Residual map (utils/t2map_utils.py:62-89) and optional R^2 from float32 maps already on the device.
@@ -671,8 +683,10 @@ template <class A>
 hipError_t launch_persistent(unsigned grid, size_t lds_samples, hipStream_t st, const LaneParams& P,
                              const float* echoes, int layout, const uint8_t* mask, int64_t n_vox, const DevMaps& dm,
                              unsigned long long* counter) {
-  auto kern = dm.trace ? fit_persistent_kernel<A, kChunkSmall, true>
-                       : (n_vox <= kSmallVolume ? fit_persistent_kernel<A, kChunkSmall> : fit_persistent_kernel<A, kChunkLarge>);
+  constexpr int W = A::kWavesPerSimd;
+  auto kern = dm.trace ? fit_persistent_kernel<A, kChunkSmall, true, W>
+                       : (n_vox <= kSmallVolume ? fit_persistent_kernel<A, kChunkSmall, false, W>
+                                                : fit_persistent_kernel<A, kChunkLarge, false, W>);
   const size_t lds = ((lds_samples / sizeof(float) + 1) & ~(size_t)1) * sizeof(float) +
                      (size_t)A::kHistDoubles * kBlock * sizeof(double) +
                      (size_t)(kBlock / 64) * kQueueCap * sizeof(uint32_t);

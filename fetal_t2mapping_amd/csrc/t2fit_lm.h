@@ -146,7 +146,7 @@ struct LmLane {
   T q[3], qn[3], d[3];   // accepted point, pending point, step that led to it
   LmEval<T> e, en;
   T lambda, nu, rel, pred, xtol;
-  double lbd[3], ubd[3];
+  double lb0;            // lower bound of k: the only per-voxel bound (no-prior mode); the others are in LaneParams
   int it, maxit;
   uint8_t status;
   bool first;
@@ -154,21 +154,26 @@ struct LmLane {
   // where the objective has one minimum at each end of the T2 interval) the fit is repeated from the
   // table start point and the lower objective wins
   int stage;
-  T qbest[3], fbest, x0q[3];
+  T qbest[3], fbest;
   uint8_t sbest;
+
+  // the table start point in (k | k^2, R, sigma^2), clipped into the box
+  T2_HD void table_start(const LaneParams& P, T* out) const {
+    auto sq = [](double v) { return v > 0.0 ? v * v : 0.0; };
+    out[0] = t2_clip(NP == 3 ? (T)sq(P.x0[0]) : (T)P.x0[0], lo[0], hi[0]);
+    out[1] = t2_clip((T)P.lm_r_x0, lo[1], hi[1]);
+    out[2] = (NP == 3) ? t2_clip((T)sq(P.x0[2]), lo[2], hi[2]) : T(0);
+  }
 
   T2_HD void init(const ObjCtx& c, const double* x0, const double* lb_, const double* ub_) {
     const LaneParams& P = *c.P;
     auto sq = [](double v) { return v > 0.0 ? v * v : 0.0; };  // |.| >= 0 side of an even parameter
-    for (int j = 0; j < 3; ++j) { lbd[j] = lb_[j]; ubd[j] = ub_[j]; }
-    lo[0] = NP == 3 ? (T)sq(lbd[0]) : (T)lbd[0];
-    hi[0] = NP == 3 ? (T)sq(ubd[0]) : (T)ubd[0];
+    lb0 = lb_[0];
+    lo[0] = NP == 3 ? (T)sq(lb_[0]) : (T)lb_[0];
+    hi[0] = NP == 3 ? (T)sq(ub_[0]) : (T)ub_[0];
     lo[1] = (T)P.lm_r_lo; hi[1] = (T)P.lm_r_hi;  // R = 1/T2 reverses the interval: 1/ub, 1/lb (make_lane_params)
-    lo[2] = (T)sq(lbd[2]); hi[2] = (T)sq(ubd[2]);
-    qn[0] = t2_clip(NP == 3 ? (T)sq(x0[0]) : (T)x0[0], lo[0], hi[0]);
-    qn[1] = t2_clip((T)P.lm_r_x0, lo[1], hi[1]);
-    qn[2] = (NP == 3) ? t2_clip((T)sq(x0[2]), lo[2], hi[2]) : T(0);
-    for (int j = 0; j < 3; ++j) x0q[j] = qn[j];
+    lo[2] = (T)sq(lb_[2]); hi[2] = (T)sq(ub_[2]);
+    table_start(P, qn);
     stage = 0;
     T ks, Rs;
     if (loglinear_seed<T>(c, ks, Rs)) {
@@ -197,9 +202,11 @@ struct LmLane {
   T2_HD void eval(const ObjCtx& c) { lm_eval<T, NP>(c, qn, en); }
 
   // the current run has ended with `status`; returns false if a second run was started instead
-  T2_HD bool finish_run() {
+  T2_HD bool finish_run(const LaneParams& P) {
     const bool at_t2_bound = q[1] <= lo[1] || q[1] >= hi[1];
     if (stage == 0 && at_t2_bound && status != T2FIT_ST_NONFINITE && it < maxit) {
+      T x0q[3];
+      table_start(P, x0q);
       bool same = true;
       for (int j = 0; j < 3; ++j) same = same && x0q[j] == q[j];
       if (!same) {
@@ -224,7 +231,7 @@ struct LmLane {
 
   T2_HD bool advance(const ObjCtx& c) {
     if (!step(c)) return false;
-    return finish_run();
+    return finish_run(*c.P);
   }
 
   T2_HD bool step(const ObjCtx& c) {
@@ -290,6 +297,9 @@ struct LmLane {
 
   T2_HD void result(const ObjCtx& c, LaneResult& out) const {
     // back to (k, T2, sigma); a coordinate sitting on a bound is snapped onto it exactly
+    const LaneParams& P = *c.P;
+    const double lbd[3] = {lb0, P.no_prior ? P.np_t2_lb : P.lb[1], P.lb[2]};
+    const double ubd[3] = {P.no_prior ? P.np_k_ub : P.ub[0], P.no_prior ? P.np_t2_ub : P.ub[1], P.ub[2]};
     // (square root and reciprocal in the solver's own precision: the iterate carries no more than that)
     out.x[0] = NP == 3 ? (q[0] <= lo[0] && lbd[0] > 0.0 ? lbd[0] : (q[0] >= hi[0] ? ubd[0] : (double)t2_sqrt(q[0])))
                        : (double)q[0];
