@@ -8,6 +8,8 @@ Results are identical to calling ``fit_volume`` per subject (voxels are independ
 from __future__ import annotations
 
 import ctypes as C
+import os
+import sys
 from concurrent.futures import ThreadPoolExecutor
 from typing import Iterable, Iterator, Optional, Tuple
 
@@ -42,6 +44,8 @@ class _Slot:
         self.dev = dev
         self.cap_e = self.cap_n = 0
         self.meta = None
+        self.d2h_queued = False
+        self.tl = None
 
     def ensure(self, n_te: int, n: int, need_h_in: bool):
         import torch
@@ -96,12 +100,27 @@ def fit_subjects(subjects: Iterable[Tuple[np.ndarray, Optional[np.ndarray]]], TE
     with torch.cuda.device(dev):
         compute = torch.cuda.current_stream()
         slots, s_in, s_out = _context(dev, depth)
-        for slot in slots:  # an abandoned earlier generator may have left copies in flight
-            if slot.meta is not None:
-                slot.ev_d2h.synchronize()
-                slot.meta = None
+        if any(slot.meta is not None for slot in slots):  # an abandoned earlier generator may have left work in flight
+            torch.cuda.synchronize(dev)
+            for slot in slots:
+                slot.meta, slot.d2h_queued, slot.tl = None, False, None
+
+        def queue_d2h(slot):
+            if slot.meta is None or slot.d2h_queued:
+                return
+            n = slot.meta[1]
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(slot.ev_fit)
+                if slot.tl is not None:
+                    slot.tl[4].record(s_out)
+                slot.h_out[: 4 * n].copy_(slot.d_out[: 4 * n], non_blocking=True)
+                slot.ev_d2h.record(s_out)
+                if slot.tl is not None:
+                    slot.tl[5].record(s_out)
+            slot.d2h_queued = True
 
         def finish(slot):
+            queue_d2h(slot)
             slot.ev_d2h.synchronize()
             shape, n = slot.meta
             if copy_out:
@@ -112,7 +131,9 @@ def fit_subjects(subjects: Iterable[Tuple[np.ndarray, Optional[np.ndarray]]], TE
             slot.meta = None
             return T2Maps(*(out[j].reshape(shape) for j in range(4)))
 
+        timeline = [] if os.environ.get("T2FIT_STREAM_TIMELINE") else None  # diagnostic: per-stage HIP-event times
         n_sub = 0
+        prev = None
         for s, (echoes, mask) in enumerate(subjects):
             n_sub = s + 1
             slot = slots[s % depth]
@@ -135,23 +156,45 @@ def fit_subjects(subjects: Iterable[Tuple[np.ndarray, Optional[np.ndarray]]], TE
                 mk = np.asarray(mask).reshape(-1)
                 # the kernels test mask != 0 themselves: one-byte masks are staged as they are
                 _parallel_copy(slot.h_mask[:n].numpy(), mk.view(np.uint8) if mk.dtype.itemsize == 1 else (mk != 0).view(np.uint8))
+            tl = None
+            if timeline is not None:
+                tl = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+                timeline.append(tl)
+                tl[0].record(s_in)
             with torch.cuda.stream(s_in):
                 slot.d_in[: n_te * n].copy_(src, non_blocking=True)
                 slot.d_mask[:n].copy_(slot.h_mask[:n], non_blocking=True)
                 slot.ev_h2d.record(s_in)
+                if tl is not None:
+                    tl[1].record(s_in)
+            # The two copy directions share one engine queue on this platform and a queued copy that waits for a
+            # kernel blocks everything behind it: the device->host copy of the PREVIOUS subject (which waits for
+            # its fit) is therefore queued only now, after this subject's host->device copy.
+            if prev is not None:
+                queue_d2h(prev)
             compute.wait_event(slot.ev_h2d)
+            if tl is not None:
+                tl[2].record(compute)
             maps = _abi.T2FitMaps()
             base = slot.d_out.data_ptr()
             maps.t2, maps.k, maps.sigma, maps.res = (base + 4 * n * j for j in range(4))
             check(lib.t2fit_volume_dev(C.byref(cfg), slot.d_in.data_ptr(), _abi.LAYOUT_TE_MAJOR, slot.d_mask.data_ptr(),
                                        n, C.byref(maps), C.c_void_p(compute.cuda_stream)))
             slot.ev_fit.record(compute)
-            with torch.cuda.stream(s_out):
-                s_out.wait_event(slot.ev_fit)
-                slot.h_out[: 4 * n].copy_(slot.d_out[: 4 * n], non_blocking=True)
-                slot.ev_d2h.record(s_out)
-            slot.meta = (shape, n)
+            if tl is not None:
+                tl[3].record(compute)
+            slot.meta, slot.d2h_queued, slot.tl = (shape, n), False, tl
+            prev = slot
+        if prev is not None:
+            queue_d2h(prev)
         for k in range(n_sub - min(depth, n_sub), n_sub):  # drain in submission order
             slot = slots[k % depth]
             if slot.meta is not None:
                 yield finish(slot)
+        if timeline:
+            torch.cuda.synchronize()
+            t0 = timeline[0][0]
+            for i, tl in enumerate(timeline):  # ms since the first copy was queued: h2d, fit, d2h as [start, end]
+                print(f"[t2fit stream] subject {i}: " + "  ".join(
+                    f"{name} {t0.elapsed_time(tl[a]):7.2f}-{t0.elapsed_time(tl[b]):7.2f}" for name, a, b in
+                    (("h2d", 0, 1), ("fit", 2, 3), ("d2h", 4, 5))), file=sys.stderr)
