@@ -119,6 +119,7 @@ def set_phantom_gt(low_field):
 def save_nifti_maps(t2_map, k_map, sigma_map, res_map, dirname, recon_img, bids_path, acq, sim, analysis):
     """utils/t2map_utils.py:18-29."""
     sitk = _sitk()
+    items = []
     for arr, tag in zip([t2_map, k_map, sigma_map, res_map], ["t2", "k", "sigma", "res"]):
         img = sitk.GetImageFromArray(arr)
         img.SetSpacing(recon_img.GetSpacing())
@@ -126,7 +127,12 @@ def save_nifti_maps(t2_map, k_map, sigma_map, res_map, dirname, recon_img, bids_
         img.SetDirection(recon_img.GetDirection())
         path = get_img_path(bids_path, acq.iloc[0], dirname)
         path = path.replace("t2map.nii.gz", "sim-" + str(sim) + f"_{tag}map_ada-{analysis}.nii.gz")
-        sitk.WriteImage(img, path)
+        items.append((img, path))
+    if hasattr(sitk, "WriteImages"):  # native writer: the four maps are compressed concurrently
+        sitk.WriteImages(items)
+    else:
+        for img, path in items:
+            sitk.WriteImage(img, path)
     print(f"T2 map saved as nifti file in {dirname}")
 
 

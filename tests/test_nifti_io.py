@@ -158,3 +158,20 @@ def test_cli_end_to_end_on_nifti_files(tmp_path, monkeypatch):
         img = nifti.ReadImage(os.path.join(out_dir, name))
         assert img.arr.dtype == np.float32 and np.array_equal(img.arr, d[key]), key
         assert np.allclose(img.GetSpacing(), d["spacing"]) and np.allclose(img.GetOrigin(), d["origin"])
+
+
+def test_threaded_gzip_members_round_trip(tmp_path):
+    """Volumes above 8 MB are written as several gzip members (one per thread): still an ordinary .gz for Python's
+    gzip module and for this reader, both as a single image and through read_stack."""
+    rng = np.random.default_rng(4)
+    vol = rng.normal(size=(40, 256, 256)).astype(np.float32)  # 10.5 MB -> 2 data members + the header member
+    p = str(tmp_path / "big.nii.gz")
+    nifti.WriteImage(nifti.GetImageFromArray(vol), p, threads=4)
+    raw = gzip.open(p).read()
+    assert len(raw) == 352 + vol.nbytes and np.array_equal(np.frombuffer(raw[352:], np.float32).reshape(vol.shape), vol)
+    assert open(p, "rb").read().count(b"\x1f\x8b\x08") >= 3
+    assert np.array_equal(nifti.ReadImage(p).arr, vol)
+    nifti.WriteImages([(nifti.GetImageFromArray(vol[:20]), str(tmp_path / "a.nii.gz")),
+                       (nifti.GetImageFromArray(vol[20:]), str(tmp_path / "b.nii.gz"))])
+    stack, _ = nifti.read_stack([str(tmp_path / "a.nii.gz"), str(tmp_path / "b.nii.gz")])
+    assert np.array_equal(stack.reshape(vol.shape), vol)
