@@ -39,6 +39,35 @@ def _sitk():
     return sitk
 
 
+_pinned = {}
+
+
+def _pinned_stack(recon_paths):
+    """Page-locked float32 staging block for one subject's echoes (kept for the next subject of the same size):
+    the decoder writes into it and the host->device copy is a DMA from where the samples lie.  None when torch
+    or a GPU is not there (the fit would fail loudly later anyway)."""
+    try:
+        import torch
+
+        from . import nifti
+
+        if not torch.cuda.is_available():
+            return None
+        with open(recon_paths[0], "rb") as f:
+            head = f.read(4096)
+        if head[:2] == b"\x1f\x8b":
+            import zlib
+
+            head = zlib.decompressobj(wbits=31).decompress(head, 352)
+        n = len(recon_paths) * int(np.prod(nifti._parse_header(head).shape))
+        if _pinned.get("n") != n:
+            _pinned.clear()
+            _pinned.update(n=n, buf=torch.empty(n, dtype=torch.float32).pin_memory())
+        return _pinned["buf"].numpy()
+    except Exception:
+        return None
+
+
 def _read_subject(sitk, recon_paths, mask_paths, label_path):
     """All volumes of one (sub, ses): echoes, masks, optional vial labels, and the last recon image (its
     geometry goes onto the maps, run_t2mapping.py:377 / utils/t2map_utils.py:22-24).  With the native
@@ -51,7 +80,7 @@ def _read_subject(sitk, recon_paths, mask_paths, label_path):
         with ThreadPoolExecutor(8) as pool:
             masks_f = pool.map(nifti.ReadImage, mask_paths)
             label_f = pool.submit(nifti.ReadImage, label_path) if label_path else None
-            stack, images = nifti.read_stack(recon_paths)
+            stack, images = nifti.read_stack(recon_paths, out=_pinned_stack(recon_paths))
             masks = [m.arr for m in masks_f]
             label = label_f.result().arr if label_f else None
         return list(stack), masks, label, images[-1]
