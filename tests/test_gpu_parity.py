@@ -465,6 +465,25 @@ def test_label_stats_match_numpy_nanmean_nanstd(t2):
         t2.label_stats(m, lab, 33)
 
 
+def test_notebook_known_answer_on_device(t2):
+    """The reference's only committed numeric known-answer (notebooks/20240910_ada_jmri.ipynb cell 26, see
+    tests/test_oracle_golden.py): nine echo times (the ninth leaves the unrolled block of the evaluation), custom
+    fit_params through the voxel seam.  HIP == oracle: 13 iterations as the notebook prints, T2 within 1e-3 ms."""
+    import copy
+
+    from oracle import t2fit_oracle as O
+    from test_oracle_golden import NOTEBOOK_MEAN, NOTEBOOK_PARAMS, NOTEBOOK_TE
+
+    want = O.fit_voxel(0, "gaussian", copy.deepcopy(NOTEBOOK_PARAMS), NOTEBOOK_TE, NOTEBOOK_MEAN[None, :], True, False)
+    x, ok, nit, fun, st = t2.fit_voxels([0], "gaussian", copy.deepcopy(NOTEBOOK_PARAMS), NOTEBOOK_TE, NOTEBOOK_MEAN[None, :],
+                                        True, False)
+    assert ok[0] and nit[0] == want[2] == 13
+    assert abs(x[0, 1] - want[0][1]) < 1e-3 and abs(x[0, 0] - want[0][0]) < 1e-2 and np.isclose(fun[0], want[3], rtol=1e-6)
+    assert abs(x[0, 1] - 117.6) < 0.03 * 117.6
+    got = t2.fit_voxel(0, "gaussian", copy.deepcopy(NOTEBOOK_PARAMS), NOTEBOOK_TE, NOTEBOOK_MEAN[None, :], True, False)
+    assert got[2] == 13 and len(got[4]) == 13 and np.isclose(got[4][-1]["f_val"], want[3], rtol=1e-6)
+
+
 def test_streamed_subjects_equal_per_subject_fits(t2):
     """Config 5 path: double-buffered host->HBM streaming of several subjects == one fit per subject."""
     from fetal_t2mapping_amd import stream, synth

@@ -98,3 +98,21 @@ def test_loglin_lane_equals_closed_form_oracle(path):
     for r in rows[:20]:
         f = np.mean((d["y"][r].astype(np.float64) - o["x"][r, 0] * np.exp(-te / o["x"][r, 1])) ** 2)
         assert np.isclose(o["fun"][r], f, rtol=1e-12)
+
+
+def test_lbfgsb_lane_reproduces_the_notebook_known_answer():
+    """The reference's one committed known-answer (tests/test_oracle_golden.py NOTEBOOK_*): the lane solver walks the
+    same 13 iterations as scipy on the printed ROI means, nine echoes (eight unrolled + one in the tail loop)."""
+    import copy
+
+    from oracle import t2fit_oracle as oracle
+    from test_oracle_golden import NOTEBOOK_MEAN, NOTEBOOK_PARAMS, NOTEBOOK_TE
+
+    want = oracle.fit_voxel(0, "gaussian", copy.deepcopy(NOTEBOOK_PARAMS), NOTEBOOK_TE, NOTEBOOK_MEAN[None, :], True, False)
+    cfg = sim.config("gaussian", True, NOTEBOOK_TE, solver="lbfgsb")
+    cfg.x0[0], cfg.x0[1] = 630.0, 165.0
+    cfg.lb[0], cfg.ub[0], cfg.lb[1], cfg.ub[1] = float(NOTEBOOK_MEAN[0]), 1e4, 10.0, 600.0
+    cfg.ftol = 1e-6
+    o = sim.fit_rows(cfg, NOTEBOOK_MEAN[None, :])
+    assert o["nit"][0] == want[2] == 13 and o["status"][0] == 1
+    assert abs(o["x"][0, 1] - want[0][1]) < 1e-3 and abs(o["x"][0, 0] - want[0][0]) < 1e-2
