@@ -3,7 +3,9 @@ N masked voxels of the bench distribution, per configuration: HIP (through the C
 (scipy loop, this host's cores) and, as the yardstick, the oracle vs itself with exp() perturbed by one
 ulp (tests/golden/make_noise_floor.py explains why that is the best any implementation can do).
 
-    python tools/parity_at_scale.py [N] > profiles/rNN_parity_at_scale.json      (on the GPU box)
+    python tools/parity_at_scale.py [N] [--all] > profiles/rNN_parity_at_scale.json      (on the GPU box)
+
+--all adds the 2-parameter no-prior and the Rician-likelihood configurations and the closed-form solver against its oracle.
 """
 import json
 import multiprocessing as mp
@@ -22,7 +24,8 @@ from scipy.optimize import minimize  # noqa: E402
 from fetal_t2mapping_amd import synth  # noqa: E402
 from oracle import t2fit_oracle as O  # noqa: E402
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 20000
+ALL = "--all" in sys.argv
 EPS = np.finfo(float).eps
 
 
@@ -42,7 +45,14 @@ def _perturbed(args):
         r = y - (p[0] ** 2 * pexp(-2 * t / p[1]) + p[2] ** 2) ** (1 / 2)
         return np.sum(r ** 2) / len(y)
 
-    fun = gauss if fit == "gaussian" else gr
+    def ric(p, t, y):  # run_t2mapping.py:157-177 with the perturbed exp()
+        from scipy.special import i0e
+
+        m = p[0] * pexp(-t / p[1])
+        xx = (m * y) / (p[2] ** 2)
+        return -np.sum((np.log(y) - np.log(p[2] ** 2)) - (y ** 2 + m ** 2) / (2 * p[2] ** 2) + (np.abs(xx) + np.log(i0e(xx))))
+
+    fun = {"gaussian": gauss, "gaussian_rician": gr, "rician": ric}[fit]
     out = []
     for v in idx:
         fp = O.fit_table(fit, True)
@@ -60,7 +70,10 @@ def main():
     report = {"n_voxels": int(len(rows)), "te_ms": te.tolist(), "cores": cores, "configs": {}}
     with mp.get_context("fork").Pool(cores) as pool:  # before the GPU is touched
         ref = {}
-        for fit, prior in (("gaussian", True), ("gaussian_rician", True), ("gaussian_rician", False)):
+        configs = [("gaussian", True), ("gaussian_rician", True), ("gaussian_rician", False)]
+        if ALL:
+            configs += [("gaussian", False), ("rician", True)]
+        for fit, prior in configs:
             r = O.fit_volume(rows, np.arange(len(rows)), te, fit, O.fit_table(fit, True), prior=prior, pool=pool)
             chunks = np.array_split(np.arange(len(rows)), cores * 4)
             pert = np.array([x for part in pool.map(_perturbed, [(c, fit, prior, te, rows, 7 + i) for i, c in enumerate(chunks)])
@@ -72,8 +85,11 @@ def main():
         x, ok, nit, fun, st = t2.fit_voxels(np.arange(len(rows)), fit, t2.fit_table(fit, True), te, rows, prior, False)
         dt = np.abs(x[:, 1] - r.t2.astype(np.float64))  # oracle maps are float32 casts
         dtp = np.abs(pert[:, 1] - r.t2.astype(np.float64))
-        xl, okl, _, funl, _ = t2.fit_voxels(np.arange(len(rows)), fit, t2.fit_table(fit, True), te, rows, prior, False,
-                                            solver="lm", precision="f32")
+        if fit != "rician":
+            xl, okl, _, funl, _ = t2.fit_voxels(np.arange(len(rows)), fit, t2.fit_table(fit, True), te, rows, prior, False,
+                                                solver="lm", precision="f32")
+        else:  # the LM lane serves the least-squares models only
+            xl, funl = np.full_like(x, np.nan), np.full(len(rows), np.nan)
         dl = np.abs(xl[:, 1] - r.t2.astype(np.float64))
         report["configs"][f"{fit}/{'prior' if prior else 'noprior'}"] = {
             "hip_lbfgsb_vs_reference": {"within_1ms": float(np.mean(dt <= 1.0)), "median_ms": float(np.median(dt)),
@@ -86,6 +102,16 @@ def main():
             "hip_lm_f32_vs_reference": {"within_1ms": float(np.mean(dl <= 1.0)), "median_ms": float(np.median(dl)),
                                         "objective_not_worse": float(np.mean(funl <= r.fun * (1 + 2e-3) + 1e-9))},
         }
+    if ALL:  # closed-form solver against its own oracle (extension: no reference counterpart)
+        for prior in (True, False):
+            want, okw = O.loglinear_fit(rows, te, O.fit_table("gaussian", True), prior=prior)
+            x, ok, _, _, _ = t2.fit_voxels(np.arange(len(rows)), "gaussian", t2.fit_table("gaussian", True), te, rows, prior,
+                                           False, solver="loglin")
+            rel = np.abs(x[:, 1] - want[:, 1]) / want[:, 1]
+            report["configs"][f"loglin/{'prior' if prior else 'noprior'}"] = {
+                "hip_vs_closed_form_oracle": {"max_rel_t2": float(rel.max()), "median_rel_t2": float(np.median(rel)),
+                                              "max_rel_k": float((np.abs(x[:, 0] - want[:, 0]) / want[:, 0]).max()),
+                                              "status_equal": float(np.mean(ok == okw))}}
     print(json.dumps(report, indent=1))
 
 
