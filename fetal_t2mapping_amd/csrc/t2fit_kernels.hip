@@ -4,7 +4,8 @@
 // Mapping: one lane fits one voxel at a time, 256-thread workgroups (4 wave64).  The fit kernels
 // are persistent: waves pull chunks of consecutive voxels from a global atomic counter and every
 // lane that finishes a voxel takes the next one (fit_persistent_kernel below); the streaming
-// kernels (residual map, mask union) use grid = ceil(N / tile) >> 256 CUs.
+// kernels (closed-form log-linear fit, residual map, mask union, per-label statistics) use
+// grid = ceil(N / tile) >> 256 CUs.
 // HBM layout: echoes (nTE, N) float32, TE-major; every sample of a fitted voxel is read once and
 // parked in LDS ([nTE][257] floats per workgroup, one column per lane, padded so the voxel-major
 // staging transpose is conflict-free).  The solver re-reads its column from LDS on every objective
