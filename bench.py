@@ -177,11 +177,10 @@ def main():
     if do_gather and a.solver == "lbfgsb" and a.reserve_cus > 0 and "T2FIT_PERSISTENT_BLOCKS" not in os.environ:
         # The reference-trajectory kernel is persistent with one workgroup per CU (its LDS-resident history fills the
         # CU): launched over every CU it leaves RCCL's all-gather kernel nowhere to run until it drains, and the
-        # gather of step i could not overlap the fit of step i+1.  A grid of (CUs - reserve) workgroups keeps a few
-        # CUs free for it.  The library reads the variable once, at its first launch.
-        cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        reserved = min(a.reserve_cus, cus - 1)
-        os.environ["T2FIT_PERSISTENT_BLOCKS"] = str(cus - reserved)
+        # gather of step i could not overlap the fit of step i+1.  T2FIT_RESERVE_CUS makes the library launch that
+        # kernel over (CUs - reserve) workgroups.  The library reads the variable once, at its first launch.
+        reserved = a.reserve_cus
+        os.environ["T2FIT_RESERVE_CUS"] = str(reserved)
     maps_b = []
     for pk in packed:
         mb = _abi.T2FitMaps()

@@ -34,6 +34,7 @@ constexpr int kLdsStride = kBlock + 1;
 bool g_use_persistent = true;  // LM: false selects the one-voxel-per-lane kernel (T2FIT_ONE_SHOT=1)
 int g_refill_min = 0;           // > 0 overrides the per-solver refill batch (T2FIT_REFILL_MIN)
 int g_persistent_blocks = 2048;  // grid of the persistent kernel (T2FIT_PERSISTENT_BLOCKS overrides)
+int g_reserve_cus = 0;           // T2FIT_RESERVE_CUS: CUs the one-workgroup-per-CU L-BFGS-B kernel leaves free
 
 thread_local std::string g_err;
 thread_local bool g_timing = false;
@@ -725,6 +726,7 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
     if (const char* e = std::getenv("T2FIT_ONE_SHOT")) g_use_persistent = std::atoi(e) == 0;
     if (const char* e = std::getenv("T2FIT_PERSISTENT_BLOCKS")) g_persistent_blocks = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("T2FIT_REFILL_MIN")) g_refill_min = std::min(64, std::max(1, std::atoi(e)));
+    if (const char* e = std::getenv("T2FIT_RESERVE_CUS")) g_reserve_cus = std::max(0, std::atoi(e));
     return true;
   }();
   (void)env_read;
@@ -751,7 +753,15 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
     // one workgroup per CU slot; not required to be co-resident (work comes from an atomic queue)
     const int kChunk = (dm.trace || n_vox <= kSmallVolume) ? kChunkSmall : kChunkLarge;
     const int64_t chunks = (n_vox + kChunk - 1) / kChunk;
-    const unsigned pgrid = (unsigned)std::min<int64_t>((chunks + 3) / 4, g_persistent_blocks);
+    unsigned pgrid = (unsigned)std::min<int64_t>((chunks + 3) / 4, g_persistent_blocks);
+    if (g_reserve_cus > 0 && cfg->solver == T2FIT_SOLVER_LBFGSB) {
+      // this kernel's workgroup fills a CU (LDS): a grid of (CUs - reserve) leaves whole CUs to kernels of other
+      // streams (RCCL's all-gather beside the next fit), which otherwise could not start before it drains
+      int dev = 0, cus = 0;
+      T2_HIP(hipGetDevice(&dev));
+      T2_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      pgrid = std::min<unsigned>(pgrid, (unsigned)std::max(1, cus - g_reserve_cus));
+    }
     hipError_t pe;
 #define T2_PERSIST(...) pe = launch_persistent<__VA_ARGS__>(pgrid, lds, st, P, echoes, layout, mask, n_vox, dm, counter)
     if (cfg->solver == T2FIT_SOLVER_LBFGSB) {
