@@ -88,9 +88,13 @@ __device__ __forceinline__ void stage_echoes(float* lds, const float* __restrict
   }
 }
 
+// kExtras = false: the caller asked for the reference's four maps only; the optional outputs are not even tested
+// for (their pointers would otherwise live in scalar registers across the whole persistent loop)
+template <bool kExtras = true>
 __device__ __forceinline__ void store_masked(const DevMaps& m, int64_t v) {
   // zeros outside the mask (run_t2mapping.py:415-418)
   m.t2[v] = 0.0f; m.k[v] = 0.0f; m.sigma[v] = 0.0f; m.res[v] = 0.0f;
+  if constexpr (!kExtras) return;
   if (m.r2) m.r2[v] = 0.0f;
   if (m.se) m.se[v] = 0.0f;
   if (m.fun) m.fun[v] = 0.0f;
@@ -112,8 +116,10 @@ __device__ __forceinline__ void store_result(const DevMaps& m, int64_t v, const 
 }
 
 // parameters and per-voxel extras only; res / r2 come from the epilogue pass
+template <bool kExtras = true>
 __device__ __forceinline__ void store_fit(const DevMaps& m, int64_t v, const LaneResult& r) {
   m.k[v] = (float)r.x[0]; m.t2[v] = (float)r.x[1]; m.sigma[v] = (float)r.x[2];
+  if constexpr (!kExtras) return;
   if (m.fun) m.fun[v] = (float)r.fun;
   if (m.nit) m.nit[v] = r.nit;
   if (m.status) m.status[v] = r.status;
@@ -297,7 +303,7 @@ template <typename T, int NPAR> struct LmLaneAdaptor {
   __device__ static void result(const Solver& s, const ObjCtx& c, LaneResult& r) { s.result(c, r); }
 };
 
-template <class A, int kChunk, bool kTrace>
+template <class A, int kChunk, bool kTrace, bool kExtras>
 __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float* __restrict__ echoes, int layout,
                                                const uint8_t* __restrict__ mask, int64_t n_vox, const DevMaps& m,
                                                unsigned long long* next_chunk, int refill_min) {
@@ -338,7 +344,7 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
       if (done) {
         LaneResult r;
         A::result(s, c, r);
-        store_fit(m, v, r);
+        store_fit<kExtras>(m, v, r);
         done = false;
       }
       const int n_need = __popcll(need);
@@ -371,7 +377,7 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
 #pragma unroll
         for (int q = 0; q < kChunk / 64; ++q) {
           const int64_t vv = base + q * 64 + lane;
-          if (vv < n_vox && !act[q]) store_masked(m, vv);
+          if (vv < n_vox && !act[q]) store_masked<kExtras>(m, vv);
         }
       }
       bool fresh = false;
@@ -432,7 +438,7 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
           for (int j = 0; j < 3; ++j)
             r.x[j] = !feasible ? (j < NP ? NAN : 0.0) : (j < NP ? t2_clip(box_x0[j], lb[j], ub[j]) : 0.0);
           r.status = !feasible ? T2FIT_ST_INFEASIBLE : T2FIT_ST_NONFINITE;
-          store_fit(m, v, r);
+          store_fit<kExtras>(m, v, r);
           busy = false;
         } else {
           if constexpr (kTrace) {  // per-iteration trace of this voxel (voxel seam only)
@@ -461,7 +467,7 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
   if (done) {  // (every exit passes through the refill block above; kept for safety)
     LaneResult r;
     A::result(s, c, r);
-    store_fit(m, v, r);
+    store_fit<kExtras>(m, v, r);
   }
 #if defined(T2_PHASE_STAMPS)
   if (lane == 0) {
@@ -477,12 +483,12 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
 // The kernel proper.  kWavesPerSimd is the occupancy the register allocator is asked to keep: 1 for the
 // float64 solvers (the L-BFGS-B lane alone holds ~340 registers), 4 for the float32 LM lane, which sits a few
 // registers above the 128-register line of four waves per SIMD without the hint.
-template <class A, int kChunk, bool kTrace = false, int kWavesPerSimd = 1>
+template <class A, int kChunk, bool kTrace = false, int kWavesPerSimd = 1, bool kExtras = true>
 __global__ __launch_bounds__(kBlock, kWavesPerSimd) void fit_persistent_kernel(const LaneParams P,
                                                                        const float* __restrict__ echoes, int layout,
                                                                        const uint8_t* __restrict__ mask, int64_t n_vox,
                                                                        DevMaps m, unsigned long long* next_chunk, int refill_min) {
-  persistent_fit<A, kChunk, kTrace>(P, echoes, layout, mask, n_vox, m, next_chunk, refill_min);
+  persistent_fit<A, kChunk, kTrace, kExtras>(P, echoes, layout, mask, n_vox, m, next_chunk, refill_min);
 }
 
 // Residual map (utils/t2map_utils.py:62-89) and optional R^2 from float32 maps already on the device.
@@ -686,9 +692,11 @@ hipError_t launch_persistent(unsigned grid, size_t lds_samples, hipStream_t st, 
                              const float* echoes, int layout, const uint8_t* mask, int64_t n_vox, const DevMaps& dm,
                              unsigned long long* counter) {
   constexpr int W = A::kWavesPerSimd;
+  const bool extras = dm.r2 || dm.se || dm.fun || dm.nit || dm.status || dm.xd || dm.fund;
   auto kern = dm.trace ? fit_persistent_kernel<A, kChunkSmall, true, W>
                        : (n_vox <= kSmallVolume ? fit_persistent_kernel<A, kChunkSmall, false, W>
-                                                : fit_persistent_kernel<A, kChunkLarge, false, W>);
+                                                : (extras ? fit_persistent_kernel<A, kChunkLarge, false, W, true>
+                                                          : fit_persistent_kernel<A, kChunkLarge, false, W, false>));
   const size_t lds = ((lds_samples / sizeof(float) + 1) & ~(size_t)1) * sizeof(float) +
                      (size_t)A::kHistDoubles * kBlock * sizeof(double) +
                      (size_t)(kBlock / 64) * kQueueCap * sizeof(uint32_t);
