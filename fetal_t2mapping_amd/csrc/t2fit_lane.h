@@ -213,7 +213,7 @@ T2_HD double t2_i0e(double x) {
       8.04490411014108831608E-1};
   if (x < 0) x = -x;
   if (x <= 8.0) return t2_chbevl(x * 0.5 - 2.0, A, 30);
-  return t2_chbevl(32.0 / x - 2.0, B, 25) / sqrt(x);
+  return t2_fdiv(t2_chbevl(t2_fdiv(32.0, x) - 2.0, B, 25), t2_sqrt_core(x));
 }
 
 // ---- objective values exactly in the reference's operation order (float64) ---------------------

@@ -380,11 +380,13 @@ struct Lbfgsb {
       const double sg2 = x[N - 1] * x[N - 1], sgp2 = x1[N - 1] * x1[N - 1];
       const double ls2 = t2_log(sg2), lsp2 = t2_log(sgp2);
       const double rt2 = t2_rcp_for_div(t2), rt2p = t2_rcp_for_div(t2p);
-      auto term = [](double kk, double E, double s2v, double ls2v, float yf) {
+      // both quotients of a term share one reciprocal per noise level (1 / (2 sigma^2) is half of 1 / sigma^2, exactly)
+      const double rs2 = t2_rcp_for_div(sg2), rsp2 = t2_rcp_for_div(sgp2);
+      auto term = [](double kk, double E, double s2v, double rs2v, double ls2v, float yf) {
         const double m = kk * E;
-        const double xx = (m * (double)yf) / s2v;
+        const double xx = t2_div_by_rcp(m * (double)yf, s2v, rs2v);
         const double a = (double)logf(yf) - ls2v;
-        const double b = ((double)(yf * yf) + m * m) / (2.0 * s2v);
+        const double b = t2_div_by_rcp((double)(yf * yf) + m * m, 2.0 * s2v, 0.5 * rs2v);
         const double dd = (xx < 0 ? -xx : xx) + t2_log(t2_i0e(xx));
         return (a - b) + dd;
       };
@@ -392,7 +394,8 @@ struct Lbfgsb {
         const float yf = c.sample(i);
         const double te = P.te[i];
         const double E = t2_exp_core(t2_div_by_rcp(-te, t2, rt2)), Ep = t2_exp_core(t2_div_by_rcp(-te, t2p, rt2p));
-        add(term(k, E, sg2, ls2, yf), term(kp, E, sg2, ls2, yf), term(k, Ep, sg2, ls2, yf), term(k, E, sgp2, lsp2, yf));
+        add(term(k, E, sg2, rs2, ls2, yf), term(kp, E, sg2, rs2, ls2, yf), term(k, Ep, sg2, rs2, ls2, yf),
+            term(k, E, sgp2, rsp2, lsp2, yf));
       };
       static_for<0, 8>([&](auto JC) {
         constexpr int J = decltype(JC)::value;
