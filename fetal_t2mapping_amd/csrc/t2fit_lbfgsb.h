@@ -45,7 +45,7 @@ template <> struct ObjTerm<T2FIT_MODEL_GAUSSIAN> {
   double k, t2;
   T2_HD void set(const double* x) { k = x[0]; t2 = x[1]; }
   T2_HD double at(const ObjCtx& c, int i) const {
-    const double r = (double)c.sample(i) - k * t2_exp(-c.P->te[i] / t2);
+    const double r = (double)c.sample(i) - k * t2_exp_core(t2_fdiv(-c.P->te[i], t2));
     return r * r;
   }
   T2_HD double finish(const ObjCtx& c, double s) const { return s / c.P->n_te; }
@@ -54,7 +54,7 @@ template <> struct ObjTerm<T2FIT_MODEL_GAUSSIAN_RICIAN> {
   double k2, t2, s2;
   T2_HD void set(const double* x) { k2 = x[0] * x[0]; t2 = x[1]; s2 = x[2] * x[2]; }
   T2_HD double at(const ObjCtx& c, int i) const {
-    const double r = (double)c.sample(i) - t2_sqrt(k2 * t2_exp(-2.0 * c.P->te[i] / t2) + s2);
+    const double r = (double)c.sample(i) - t2_sqrt_core(k2 * t2_exp_core(t2_fdiv(-2.0 * c.P->te[i], t2)) + s2);
     return r * r;
   }
   T2_HD double finish(const ObjCtx& c, double s) const { return s / c.P->n_te; }
@@ -64,10 +64,10 @@ template <> struct ObjTerm<T2FIT_MODEL_RICIAN> {
   T2_HD void set(const double* x) { k = x[0]; t2 = x[1]; s2 = x[2] * x[2]; ls2 = t2_log(s2); }
   T2_HD double at(const ObjCtx& c, int i) const {
     const float yf = c.sample(i);
-    const double m = k * t2_exp(-c.P->te[i] / t2);
-    const double xx = (m * (double)yf) / s2;
+    const double m = k * t2_exp_core(t2_fdiv(-c.P->te[i], t2));
+    const double xx = t2_fdiv(m * (double)yf, s2);
     const double a = (double)logf(yf) - ls2;
-    const double b = ((double)(yf * yf) + m * m) / (2.0 * s2);
+    const double b = t2_fdiv((double)(yf * yf) + m * m, 2.0 * s2);
     const double d = (xx < 0 ? -xx : xx) + t2_log(t2_i0e(xx));
     return (a - b) + d;
   }
