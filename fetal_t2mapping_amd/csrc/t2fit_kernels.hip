@@ -876,24 +876,32 @@ int t2fit_volume_host(const t2fit_config* cfg, const float* echoes, int layout, 
     return fail(T2FIT_E_INVALID, "maps->t2/k/sigma/res must be non-NULL");
   if (n_vox == 0) return T2FIT_OK;
   T2_HIP(hipSetDevice(device));
-  hipStream_t st;
-  T2_HIP(hipStreamCreate(&st));
-  const size_t nb_e = (size_t)n_vox * cfg->n_te * sizeof(float);
-  // one allocation: echoes | 7 float maps | nit | mask | status
-  const size_t off_maps = (nb_e + 255) & ~(size_t)255;
-  const size_t map_b = (((size_t)n_vox * 4) + 255) & ~(size_t)255;
-  const size_t off_nit = off_maps + 7 * map_b;
-  const size_t off_mask = off_nit + map_b;
-  const size_t byte_b = ((size_t)n_vox + 255) & ~(size_t)255;
-  const size_t off_status = off_mask + byte_b;
-  const size_t total = off_status + byte_b;
+  const int n_te = cfg->n_te;
+  // Large volumes of the slow (reference-trajectory) solver go through in a few slabs of voxels (voxels are
+  // independent, a slab's result does not depend on the split): the host->device copy of slab s+1 and the
+  // device->host copy of slab s-1 run beside the fit of slab s, each direction on its own stream.  Measured on
+  // 256^3 x 8 TE from pageable numpy buffers: 69 ms in one piece, 55 ms in four slabs; more slabs, or slabs for
+  // the fast solvers (whose time is all copies), lose to the per-copy overhead of pageable transfers.  Slab
+  // lengths are multiples of 4096 voxels so that every slab keeps the alignment the vectorised kernels want.
+  const int64_t kSlabMin = 4 << 20;
+  int n_slabs = cfg->solver == T2FIT_SOLVER_LBFGSB ? (int)std::min<int64_t>(4, std::max<int64_t>(1, n_vox / kSlabMin)) : 1;
+  if (const char* e = std::getenv("T2FIT_HOST_SLABS")) n_slabs = std::max(1, std::min(64, std::atoi(e)));
+  const int64_t slab = (((n_vox + n_slabs - 1) / n_slabs) + 4095) & ~(int64_t)4095;
+  n_slabs = (int)((n_vox + slab - 1) / slab);
+  hipStream_t s_in = nullptr, s_fit = nullptr, s_out = nullptr;
+  std::vector<hipEvent_t> ev_in(n_slabs, nullptr), ev_fit(n_slabs, nullptr);
   char* buf = nullptr;
-  hipError_t e = hipMalloc((void**)&buf, total);
-  if (e != hipSuccess) {
-    (void)hipStreamDestroy(st);
-    return fail(T2FIT_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
-  }
-  auto cleanup = [&]() { (void)hipFree(buf); (void)hipStreamDestroy(st); };
+  auto cleanup = [&]() {
+    if (s_in) (void)hipStreamSynchronize(s_in);
+    if (s_fit) (void)hipStreamSynchronize(s_fit);
+    if (s_out) (void)hipStreamSynchronize(s_out);
+    for (auto& ev : ev_in) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : ev_fit) if (ev) (void)hipEventDestroy(ev);
+    if (buf) (void)hipFree(buf);
+    if (s_in) (void)hipStreamDestroy(s_in);
+    if (s_fit) (void)hipStreamDestroy(s_fit);
+    if (s_out) (void)hipStreamDestroy(s_out);
+  };
 #define T2_HIP_C(call)                                                          \
   do {                                                                          \
     hipError_t e_ = (call);                                                     \
@@ -902,26 +910,62 @@ int t2fit_volume_host(const t2fit_config* cfg, const float* echoes, int layout, 
       return fail(T2FIT_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     }                                                                           \
   } while (0)
-  T2_HIP_C(hipMemcpyAsync(buf, echoes, nb_e, hipMemcpyHostToDevice, st));
-  uint8_t* dmask = nullptr;
-  if (mask) {
-    dmask = (uint8_t*)(buf + off_mask);
-    T2_HIP_C(hipMemcpyAsync(dmask, mask, (size_t)n_vox, hipMemcpyHostToDevice, st));
-  }
+  T2_HIP_C(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+  T2_HIP_C(hipStreamCreateWithFlags(&s_fit, hipStreamNonBlocking));
+  T2_HIP_C(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+  const size_t nb_e = (size_t)n_vox * n_te * sizeof(float);
+  // one allocation: echoes (slab after slab, each (n_te, len) or (len, n_te)) | 7 float maps | nit | mask | status
+  const size_t off_maps = (nb_e + 255) & ~(size_t)255;
+  const size_t map_b = (((size_t)n_vox * 4) + 255) & ~(size_t)255;
+  const size_t off_nit = off_maps + 7 * map_b;
+  const size_t off_mask = off_nit + map_b;
+  const size_t byte_b = ((size_t)n_vox + 255) & ~(size_t)255;
+  const size_t off_status = off_mask + byte_b;
+  const size_t total = off_status + byte_b;
+  T2_HIP_C(hipMalloc((void**)&buf, total));
   float* fm[7];
   for (int j = 0; j < 7; ++j) fm[j] = (float*)(buf + off_maps + j * map_b);
-  DevMaps dm{fm[0], fm[1], fm[2], fm[3], maps->r2 ? fm[4] : nullptr, maps->fun ? fm[5] : nullptr,
-             maps->t2_se ? fm[6] : nullptr,
-             maps->nit ? (int32_t*)(buf + off_nit) : nullptr, maps->status ? (uint8_t*)(buf + off_status) : nullptr,
-             nullptr, nullptr};
-  rc = launch_fit(cfg, (const float*)buf, layout, dmask, n_vox, dm, st);
-  if (rc != T2FIT_OK) { cleanup(); return rc; }
   float* host_f[7] = {maps->t2, maps->k, maps->sigma, maps->res, maps->r2, maps->fun, maps->t2_se};
-  for (int j = 0; j < 7; ++j)
-    if (host_f[j]) T2_HIP_C(hipMemcpyAsync(host_f[j], fm[j], (size_t)n_vox * 4, hipMemcpyDeviceToHost, st));
-  if (maps->nit) T2_HIP_C(hipMemcpyAsync(maps->nit, buf + off_nit, (size_t)n_vox * 4, hipMemcpyDeviceToHost, st));
-  if (maps->status) T2_HIP_C(hipMemcpyAsync(maps->status, buf + off_status, (size_t)n_vox, hipMemcpyDeviceToHost, st));
-  T2_HIP_C(hipStreamSynchronize(st));
+  const bool want[7] = {true, true, true, true, maps->r2 != nullptr, maps->fun != nullptr, maps->t2_se != nullptr};
+  auto copy_out = [&](int k) -> hipError_t {  // maps of slab k, after its fit
+    const int64_t lo = (int64_t)k * slab, len = std::min<int64_t>(slab, n_vox - lo);
+    hipError_t e = hipStreamWaitEvent(s_out, ev_fit[k], 0);
+    for (int j = 0; j < 7 && e == hipSuccess; ++j)
+      if (want[j]) e = hipMemcpyAsync(host_f[j] + lo, fm[j] + lo, (size_t)len * 4, hipMemcpyDeviceToHost, s_out);
+    if (e == hipSuccess && maps->nit)
+      e = hipMemcpyAsync(maps->nit + lo, buf + off_nit + (size_t)lo * 4, (size_t)len * 4, hipMemcpyDeviceToHost, s_out);
+    if (e == hipSuccess && maps->status)
+      e = hipMemcpyAsync(maps->status + lo, buf + off_status + lo, (size_t)len, hipMemcpyDeviceToHost, s_out);
+    return e;
+  };
+  for (int k = 0; k < n_slabs; ++k) {
+    const int64_t lo = (int64_t)k * slab, len = std::min<int64_t>(slab, n_vox - lo);
+    float* d_e = (float*)buf + (size_t)lo * n_te;  // this slab's block of the device stack
+    if (layout == T2FIT_LAYOUT_TE_MAJOR)           // n_te rows of `len` samples out of planes of n_vox
+      T2_HIP_C(hipMemcpy2DAsync(d_e, (size_t)len * 4, echoes + lo, (size_t)n_vox * 4, (size_t)len * 4, (size_t)n_te,
+                                hipMemcpyHostToDevice, s_in));
+    else
+      T2_HIP_C(hipMemcpyAsync(d_e, echoes + (size_t)lo * n_te, (size_t)len * n_te * 4, hipMemcpyHostToDevice, s_in));
+    uint8_t* dmask = nullptr;
+    if (mask) {
+      dmask = (uint8_t*)(buf + off_mask) + lo;
+      T2_HIP_C(hipMemcpyAsync(dmask, mask + lo, (size_t)len, hipMemcpyHostToDevice, s_in));
+    }
+    T2_HIP_C(hipEventCreateWithFlags(&ev_in[k], hipEventDisableTiming));
+    T2_HIP_C(hipEventCreateWithFlags(&ev_fit[k], hipEventDisableTiming));
+    T2_HIP_C(hipEventRecord(ev_in[k], s_in));
+    T2_HIP_C(hipStreamWaitEvent(s_fit, ev_in[k], 0));
+    DevMaps dm{fm[0] + lo, fm[1] + lo, fm[2] + lo, fm[3] + lo, maps->r2 ? fm[4] + lo : nullptr,
+               maps->fun ? fm[5] + lo : nullptr, maps->t2_se ? fm[6] + lo : nullptr,
+               maps->nit ? (int32_t*)(buf + off_nit) + lo : nullptr,
+               maps->status ? (uint8_t*)(buf + off_status) + lo : nullptr, nullptr, nullptr};
+    rc = launch_fit(cfg, d_e, layout, dmask, len, dm, s_fit);
+    if (rc != T2FIT_OK) { cleanup(); return rc; }
+    T2_HIP_C(hipEventRecord(ev_fit[k], s_fit));
+    if (k > 0) T2_HIP_C(copy_out(k - 1));  // queued after this slab's host->device copy (one shared copy queue)
+  }
+  T2_HIP_C(copy_out(n_slabs - 1));
+  T2_HIP_C(hipStreamSynchronize(s_out));
   cleanup();
   return T2FIT_OK;
 }

@@ -718,3 +718,30 @@ def test_iteration_traces_match_reference_callbacks(t2):
     d = np.load(os.path.join(GOLDEN, "voxels_lf_gaussian_prior_te8.npz"))
     p, success, n_it, ferr, info = t2.fit_voxel(20, "gaussian", _table(t2, d), d["te"], d["y"], True, False)
     assert len(p) == 2 and isinstance(success, bool) and n_it == len(info) and set(info[0]) == {"f_val", "grad_norm", "step_size"}
+
+
+def test_host_entry_slab_pipeline_equals_single_piece(t2, monkeypatch):
+    """t2fit_volume_host sends large volumes of the slow solver through in slabs (copies beside fits); the slab
+    count can be forced with T2FIT_HOST_SLABS: any split gives the maps of the single-piece call bit for bit,
+    for both layouts, with extras, ragged tail included."""
+    from fetal_t2mapping_amd import synth
+
+    echoes, mask, te = synth.brain_volume((5, 33, 67), 6, seed=31)   # 11,055 voxels: not a multiple of anything
+    table = t2.fit_table("gaussian_rician", True)
+    monkeypatch.setenv("T2FIT_HOST_SLABS", "1")
+    one = t2.fit_volume(echoes, mask, te, "gaussian_rician", table, extras=True)
+    vm = np.ascontiguousarray(np.moveaxis(echoes, 0, -1))
+    for slabs in ("2", "3"):
+        monkeypatch.setenv("T2FIT_HOST_SLABS", slabs)
+        for got in (t2.fit_volume(echoes, mask, te, "gaussian_rician", table, extras=True),
+                    t2.fit_volume(vm, mask, te, "gaussian_rician", table, extras=True, layout="voxel_major"),
+                    t2.fit_volume(echoes, None, te, "gaussian_rician", table, solver="lm", precision="f32")):
+            if got.status is None:  # the no-mask LM call: compare with its own single-piece run
+                monkeypatch.setenv("T2FIT_HOST_SLABS", "1")
+                ref = t2.fit_volume(echoes, None, te, "gaussian_rician", table, solver="lm", precision="f32")
+                monkeypatch.setenv("T2FIT_HOST_SLABS", slabs)
+                names = ("t2", "k", "sigma", "res")
+            else:
+                ref, names = one, ("t2", "k", "sigma", "res", "r2", "fun", "nit", "status", "t2_se")
+            for name in names:
+                assert np.array_equal(getattr(got, name), getattr(ref, name), equal_nan=True), (slabs, name)
