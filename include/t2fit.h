@@ -136,7 +136,9 @@ int t2fit_volume_dev(const t2fit_config *cfg, const float *echoes_dev, int layou
                      const uint8_t *mask_dev, int64_t n_vox, const t2fit_maps *maps, void *stream);
 
 /* Same seam with host buffers (numpy arrays): allocates device staging, copies in, fits, copies
- * the requested maps out, synchronises.  `device` = HIP device ordinal. */
+ * the requested maps out, synchronises.  `device` = HIP device ordinal.  Large volumes of the L-BFGS-B
+ * solver are sent through in a few voxel slabs so that copies run beside fits; the maps do not depend
+ * on the split (voxels are independent). */
 int t2fit_volume_host(const t2fit_config *cfg, const float *echoes, int layout, const uint8_t *mask,
                       int64_t n_vox, const t2fit_maps *maps, int device);
 
