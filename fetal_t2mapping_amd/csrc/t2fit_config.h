@@ -89,11 +89,11 @@ inline int config_check(const t2fit_config* c, const char** why) {
     if (c->lb[j] > c->ub[j]) { *why = "table bounds have lb > ub"; return T2FIT_E_BOUNDS; }
   }
   if (!(c->lb[1] > 0.0) && !c->no_prior) { *why = "T2 lower bound must be positive"; return T2FIT_E_INVALID; }
-  // the objective evaluations use exp() without underflow handling (t2_exp_core): -2 TE / T2 must stay above
-  // about -1000 over the whole box (the reference's tables give -60 at most)
+  // the objective evaluations use exp() without the library's range selects (t2_exp_core): exact, denormals and
+  // underflow to 0 included, while the argument's exponent fits an int, i.e. for -2 TE / T2 above -1.4e9
   const double t2_min = c->no_prior ? c->noprior_t2_lb : c->lb[1];
-  if (!(t2_min > 0.0) || 2.0 * c->te_ms[c->n_te - 1] / t2_min > 1000.0) {
-    *why = "echo times too long for the T2 lower bound (2 TE / T2 must not exceed 1000)";
+  if (!(t2_min > 0.0) || 2.0 * c->te_ms[c->n_te - 1] / t2_min > 1.0e9) {
+    *why = "echo times absurdly long for the T2 lower bound (2 TE / T2 must not exceed 1e9)";
     return T2FIT_E_INVALID;
   }
   return T2FIT_OK;

@@ -110,8 +110,9 @@ T2_HD float t2_sqrt(float x) { return sqrtf(x); }
 
 // exp() and sqrt() of the objective evaluations, device side: the device library's own float64 sequences
 // (same constants, same operations, same order: bit-identical results) without their range handling.
-// exp: arguments here are -te/T2 or -2te/T2 with T2 >= the lower bound, i.e. in (-1075, 0]: the
-// overflow / underflow selects (two compares, four selects per call) are dead code.  sqrt: arguments are
+// exp: arguments here are -te/T2 or -2te/T2 with T2 >= the lower bound, never positive: the overflow select is
+// dead code, and ldexp() already delivers the denormal and zero results of the underflow select (checked against
+// the library down to -1.4e9; config_check keeps the argument above that).  sqrt: arguments are
 // k^2 E + sigma^2 in [0, 1e10]: the 2^-767 rescaling never triggers; zero is kept exact by one select.
 #if defined(__HIP_DEVICE_COMPILE__)
 T2_HD double t2_exp_core(double x) {
