@@ -508,6 +508,18 @@ def test_streamed_subjects_equal_per_subject_fits(t2):
     for g, a in zip(got, again):
         for name in ("t2", "k", "sigma", "res"):
             assert np.array_equal(getattr(g, name), getattr(a, name), equal_nan=True)
+    # pipeline depth 1 (every result handed out before the next subject is staged) and 3
+    for depth in (1, 3):
+        deep = list(stream.fit_subjects(subs, te, "gaussian_rician", table, solver="lm", precision="f32", depth=depth))
+        for g, a in zip(got, deep):
+            for name in ("t2", "k", "sigma", "res"):
+                assert np.array_equal(getattr(g, name), getattr(a, name), equal_nan=True), depth
+    # an abandoned generator leaves work in flight: the next call starts clean
+    gen = stream.fit_subjects(subs, te, "gaussian_rician", table, solver="lm", precision="f32")
+    next(gen)
+    del gen
+    redo = list(stream.fit_subjects(subs[:2], te, "gaussian_rician", table, solver="lm", precision="f32"))
+    assert np.array_equal(redo[1].t2, got[1].t2, equal_nan=True)
     stream.release()
 
 
