@@ -36,8 +36,10 @@ def build(force: bool = False, verbose: bool = False, extra=()) -> str:
     if not force and up_to_date():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
+    # -ffp-contract=off: the lane solvers say where a multiply-add is fused (fma()) and where numpy's / the
+    # library's two roundings are kept; results then do not depend on how the compiler happens to group code
     cmd = [hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc",
-           "-Wall", "-Wno-unused-function", *extra, "-o", LIB, *SOURCES]
+           "-ffp-contract=off", "-Wall", "-Wno-unused-function", *extra, "-o", LIB, *SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -35,6 +35,8 @@ bool g_use_persistent = true;  // LM: false selects the one-voxel-per-lane kerne
 int g_refill_min = 0;           // > 0 overrides the per-solver refill batch (T2FIT_REFILL_MIN)
 int g_persistent_blocks = 2048;  // grid of the persistent kernel (T2FIT_PERSISTENT_BLOCKS overrides)
 int g_reserve_cus = 0;           // T2FIT_RESERVE_CUS: CUs the one-workgroup-per-CU L-BFGS-B kernel leaves free
+bool g_nte_special = true;       // T2FIT_NTE_SPECIAL=0: always the generic-echo-count lane (A/B switch)
+int g_park_min = 1;              // T2FIT_PARK_MIN: lanes of a wave that must be waiting for begin() before it runs (A/B switch)
 
 thread_local std::string g_err;
 thread_local bool g_timing = false;
@@ -280,14 +282,17 @@ constexpr int kChunkLarge = 256;  // voxels a wave takes from the global queue a
 constexpr int kChunkSmall = 64;   // small volumes (phantoms): more, smaller chunks so that every wave gets work
 constexpr int64_t kSmallVolume = 1 << 21;
 constexpr int kQueueCap = 64 + kChunkLarge;
+constexpr int kDiagBlocks = 11, kDiagWords = 3 * kDiagBlocks;  // -DT2_PHASE_STAMPS: (cycles, lanes, entries) per block
+constexpr int kCounterWords = 16 + kDiagWords;                  // chunk counter + diagnostic totals
 
 // what the persistent kernel needs to know about a resumable lane solver
-template <int MODEL> struct LbfgsbLane {
-  using Solver = Lbfgsb<MODEL>;
+template <int MODEL, int NTE = 0> struct LbfgsbLane {
+  using Solver = Lbfgsb<MODEL, NTE>;
   static constexpr int NP = Solver::N;
   static constexpr int kHistDoubles = 2 * Solver::M * Solver::N;  // correction pairs, per lane, in LDS
   static constexpr int kWavesPerSimd = 1;
   static constexpr int kRefillMin = 8;   // measured on MI355X: 1 -> 28.1 ms, 8 -> 26.8 ms, 16 -> 27.6 ms
+  static constexpr bool kSplit = true;   // advance() = digest() + begin(): the kernel may batch begin() (T2FIT_PARK_MIN)
   __device__ static void init(Solver& s, const ObjCtx&, const double* x0, const double* lb, const double* ub,
                               double* hist) { s.init(x0, lb, ub, hist, kBlock); }
   __device__ static void result(const Solver& s, const ObjCtx&, LaneResult& r) { s.result(r); }
@@ -298,6 +303,7 @@ template <typename T, int NPAR> struct LmLaneAdaptor {
   static constexpr int kHistDoubles = 0;
   static constexpr int kWavesPerSimd = sizeof(T) == 4 ? 4 : 1;
   static constexpr int kRefillMin = 24;  // measured (f32, 3 parameters, MI355X): 8 -> 1.62 ms, 16 -> 1.42 ms, 24 -> 1.35 ms, 32 -> 1.35 ms
+  static constexpr bool kSplit = false;
   __device__ static void init(Solver& s, const ObjCtx& c, const double* x0, const double* lb, const double* ub,
                               double*) { s.init(c, x0, lb, ub); }
   __device__ static void result(const Solver& s, const ObjCtx& c, LaneResult& r) { s.result(c, r); }
@@ -306,7 +312,7 @@ template <typename T, int NPAR> struct LmLaneAdaptor {
 template <class A, int kChunk, bool kTrace, bool kExtras>
 __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float* __restrict__ echoes, int layout,
                                                const uint8_t* __restrict__ mask, int64_t n_vox, const DevMaps& m,
-                                               unsigned long long* next_chunk, int refill_min) {
+                                               unsigned long long* next_chunk, int refill_min, int park_min) {
   extern __shared__ float lds[];
   constexpr int NP = A::NP;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -328,17 +334,21 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
   double box_x0[3], box_lb[3], box_ub[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) { box_x0[j] = P.x0[j]; box_lb[j] = P.lb[j]; box_ub[j] = P.ub[j]; }
-#if defined(T2_PHASE_STAMPS)  // diagnostic build only: where do a wave's cycles go?
-  unsigned long long st_refill = 0, st_eval = 0, st_adv = 0, st_t = __builtin_amdgcn_s_memtime();
-#define T2_STAMP(acc) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc += n_ - st_t; st_t = n_; }
-#else
-#define T2_STAMP(acc)
+#if defined(T2_PHASE_STAMPS)  // diagnostic build only: where do a wave's cycles go?  (per-wave counters in LDS)
+  unsigned long long* diag = reinterpret_cast<unsigned long long*>(queue - wave * kQueueCap + (kBlock / 64) * kQueueCap) +
+                             wave * kDiagWords;
+  if (lane < kDiagWords) diag[lane] = 0ull;
+  c.diag = diag;
+  const unsigned long long st_all = __builtin_amdgcn_s_memtime();
 #endif
+  bool parked = false;  // split solvers: digest() done, begin() pending (see park_min below)
+  int pend = 0;
   for (;;) {
     // Refill in batches: the refill path (sample loads, seed / set-up) runs with only the idle lanes
     // active, so it is entered when at least refill_min lanes are idle (or nothing is running).
     const unsigned long long need = __ballot(!busy);
     if (__popcll(need) >= refill_min || need == ~0ull) {
+      T2_BLK_T0(t_rf)
       // lanes that finished since the last refill hand in their results here, together, rather than one
       // or two at a time in the round they finished (the conversion and the stores are divergent code)
       if (done) {
@@ -450,19 +460,42 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
           A::init(s, c, box_x0, lb, ub, hist);
         }
       }
+      T2_BLK_END(c, 8, t_rf)
     }
-    T2_STAMP(st_refill)
     if (__ballot(busy) == 0ull) {
       if (!chunks_left && q_count == 0) break;
       continue;
     }
-    if (busy) s.eval(c);
-    T2_STAMP(st_eval)
-    if (busy && s.advance(c)) {
-      busy = false;
-      done = true;
+    if constexpr (A::kSplit) {
+      // One round: every lane with a point to evaluate evaluates it (uniform code) and digests the result; lanes
+      // whose line search has ended then run begin() (B, Cauchy point, subspace step, line-search set-up).
+      // park_min > 1 holds those lanes back until that many of the wave are waiting (or no lane has anything to
+      // evaluate), so that begin() runs with more lanes active; results do not depend on it.
+      if (busy && !parked) {
+        T2_BLK_T0(t_ev)
+        s.eval(c);
+        T2_BLK_END(c, 7, t_ev)
+        pend = s.digest(c);
+        if (pend == A::Solver::GO_DONE) { busy = false; done = true; }
+        else if (pend != A::Solver::GO_TRIAL) parked = true;
+      }
+      const unsigned long long pb = __ballot(parked);
+      if (pb != 0ull && (__popcll(pb) >= park_min || __ballot(busy && !parked) == 0ull)) {
+        if (parked) {
+          parked = false;
+          T2_BLK_T0(t_bg)
+          const bool ended = s.begin(c, pend);
+          T2_BLK_END(c, 9, t_bg)
+          if (ended) { busy = false; done = true; }
+        }
+      }
+    } else {
+      if (busy) s.eval(c);
+      if (busy && s.advance(c)) {
+        busy = false;
+        done = true;
+      }
     }
-    T2_STAMP(st_adv)
   }
   if (done) {  // (every exit passes through the refill block above; kept for safety)
     LaneResult r;
@@ -470,13 +503,8 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
     store_fit<kExtras>(m, v, r);
   }
 #if defined(T2_PHASE_STAMPS)
-  if (lane == 0) {
-    atomicAdd(next_chunk + 1, st_refill);
-    atomicAdd(next_chunk + 2, st_eval);
-    atomicAdd(next_chunk + 3, st_adv);
-    if constexpr (A::kHistDoubles > 0)
-      for (int j = 0; j < 6; ++j) atomicAdd(next_chunk + 4 + j, s.stamp[j]);
-  }
+  if (lane == 0) diag[3 * 10] += __builtin_amdgcn_s_memtime() - st_all;  // block 10: the wave's whole life
+  if (lane < kDiagWords) atomicAdd(next_chunk + 16 + lane, diag[lane]);
 #endif
 }
 
@@ -487,8 +515,9 @@ template <class A, int kChunk, bool kTrace = false, int kWavesPerSimd = 1, bool 
 __global__ __launch_bounds__(kBlock, kWavesPerSimd) void fit_persistent_kernel(const LaneParams P,
                                                                        const float* __restrict__ echoes, int layout,
                                                                        const uint8_t* __restrict__ mask, int64_t n_vox,
-                                                                       DevMaps m, unsigned long long* next_chunk, int refill_min) {
-  persistent_fit<A, kChunk, kTrace, kExtras>(P, echoes, layout, mask, n_vox, m, next_chunk, refill_min);
+                                                                       DevMaps m, unsigned long long* next_chunk, int refill_min,
+                                                                       int park_min) {
+  persistent_fit<A, kChunk, kTrace, kExtras>(P, echoes, layout, mask, n_vox, m, next_chunk, refill_min, park_min);
 }
 
 // Residual map (utils/t2map_utils.py:62-89) and optional R^2 from float32 maps already on the device.
@@ -687,26 +716,47 @@ FitKernel pick_kernel(const t2fit_config& c) {
   return nullptr;  // the L-BFGS-B solver runs in the persistent kernel
 }
 
-template <class A>
+// kLargeOnly: instantiate the two large-volume kernels only (the echo-count specialisations; small volumes and
+// traced voxel batches use the generic lane, where compile time buys nothing)
+template <class A, bool kLargeOnly = false>
 hipError_t launch_persistent(unsigned grid, size_t lds_samples, hipStream_t st, const LaneParams& P,
                              const float* echoes, int layout, const uint8_t* mask, int64_t n_vox, const DevMaps& dm,
                              unsigned long long* counter) {
   constexpr int W = A::kWavesPerSimd;
   const bool extras = dm.r2 || dm.se || dm.fun || dm.nit || dm.status || dm.xd || dm.fund;
-  auto kern = dm.trace ? fit_persistent_kernel<A, kChunkSmall, true, W>
-                       : (n_vox <= kSmallVolume ? fit_persistent_kernel<A, kChunkSmall, false, W>
-                                                : (extras ? fit_persistent_kernel<A, kChunkLarge, false, W, true>
-                                                          : fit_persistent_kernel<A, kChunkLarge, false, W, false>));
+  auto kern = extras ? fit_persistent_kernel<A, kChunkLarge, false, W, true>
+                     : fit_persistent_kernel<A, kChunkLarge, false, W, false>;
+  if constexpr (!kLargeOnly) {
+    if (dm.trace) kern = fit_persistent_kernel<A, kChunkSmall, true, W>;
+    else if (n_vox <= kSmallVolume) kern = fit_persistent_kernel<A, kChunkSmall, false, W>;
+  }
   const size_t lds = ((lds_samples / sizeof(float) + 1) & ~(size_t)1) * sizeof(float) +
                      (size_t)A::kHistDoubles * kBlock * sizeof(double) +
-                     (size_t)(kBlock / 64) * kQueueCap * sizeof(uint32_t);
+                     (size_t)(kBlock / 64) * kQueueCap * sizeof(uint32_t)
+#if defined(T2_PHASE_STAMPS)
+                     + (size_t)(kBlock / 64) * kDiagWords * sizeof(unsigned long long)
+#endif
+      ;
   // > 64 KiB of dynamic LDS (the correction pairs of 256 lanes) has to be opted into
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox, dm, counter,
-                     g_refill_min > 0 ? g_refill_min : A::kRefillMin);
+                     g_refill_min > 0 ? g_refill_min : A::kRefillMin, g_park_min);
   return hipGetLastError();
+}
+
+// reference-trajectory lane for `model`, specialised for the common echo-train lengths on large volumes
+template <int MODEL>
+hipError_t launch_lbfgsb(int n_te, bool large, unsigned grid, size_t lds_samples, hipStream_t st, const LaneParams& P,
+                         const float* echoes, int layout, const uint8_t* mask, int64_t n_vox, const DevMaps& dm,
+                         unsigned long long* counter) {
+  if (large && g_nte_special) {
+    if (n_te == 8) return launch_persistent<LbfgsbLane<MODEL, 8>, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);
+    if (n_te == 6) return launch_persistent<LbfgsbLane<MODEL, 6>, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);
+    if (n_te == 3) return launch_persistent<LbfgsbLane<MODEL, 3>, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);
+  }
+  return launch_persistent<LbfgsbLane<MODEL>>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);
 }
 
 int check_common(const t2fit_config* cfg, const void* echoes, int layout, int64_t n_vox) {
@@ -735,6 +785,8 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
     if (const char* e = std::getenv("T2FIT_PERSISTENT_BLOCKS")) g_persistent_blocks = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("T2FIT_REFILL_MIN")) g_refill_min = std::min(64, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("T2FIT_RESERVE_CUS")) g_reserve_cus = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("T2FIT_NTE_SPECIAL")) g_nte_special = std::atoi(e) != 0;
+    if (const char* e = std::getenv("T2FIT_PARK_MIN")) g_park_min = std::min(64, std::max(1, std::atoi(e)));
     return true;
   }();
   (void)env_read;
@@ -747,8 +799,8 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
   if (persistent && n_vox >= 0xffffffffLL) return fail(T2FIT_E_INVALID, "n_vox must be below 2^32 per call");
   unsigned long long* counter = nullptr;
   if (persistent) {
-    T2_HIP(hipMallocAsync((void**)&counter, 16 * sizeof(unsigned long long), st));
-    T2_HIP(hipMemsetAsync(counter, 0, 16 * sizeof(unsigned long long), st));
+    T2_HIP(hipMallocAsync((void**)&counter, kCounterWords * sizeof(unsigned long long), st));
+    T2_HIP(hipMemsetAsync(counter, 0, kCounterWords * sizeof(unsigned long long), st));
   }
   if (g_timing) {
     if (!g_ev0) {
@@ -773,9 +825,12 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
     hipError_t pe;
 #define T2_PERSIST(...) pe = launch_persistent<__VA_ARGS__>(pgrid, lds, st, P, echoes, layout, mask, n_vox, dm, counter)
     if (cfg->solver == T2FIT_SOLVER_LBFGSB) {
-      if (cfg->model == T2FIT_MODEL_GAUSSIAN) T2_PERSIST(LbfgsbLane<T2FIT_MODEL_GAUSSIAN>);
-      else if (cfg->model == T2FIT_MODEL_GAUSSIAN_RICIAN) T2_PERSIST(LbfgsbLane<T2FIT_MODEL_GAUSSIAN_RICIAN>);
-      else T2_PERSIST(LbfgsbLane<T2FIT_MODEL_RICIAN>);
+      const bool large = !dm.trace && n_vox > kSmallVolume;
+#define T2_LBFGSB(M) pe = launch_lbfgsb<M>(cfg->n_te, large, pgrid, lds, st, P, echoes, layout, mask, n_vox, dm, counter)
+      if (cfg->model == T2FIT_MODEL_GAUSSIAN) T2_LBFGSB(T2FIT_MODEL_GAUSSIAN);
+      else if (cfg->model == T2FIT_MODEL_GAUSSIAN_RICIAN) T2_LBFGSB(T2FIT_MODEL_GAUSSIAN_RICIAN);
+      else T2_LBFGSB(T2FIT_MODEL_RICIAN);
+#undef T2_LBFGSB
     } else if (cfg->precision == T2FIT_PREC_F32) {
       if (cfg->model == T2FIT_MODEL_GAUSSIAN) T2_PERSIST(LmLaneAdaptor<float, 2>);
       else T2_PERSIST(LmLaneAdaptor<float, 3>);
@@ -805,16 +860,20 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
     g_ev_valid = true;
   }
 #if defined(T2_PHASE_STAMPS)
-  if (counter) {
-    unsigned long long h[16];
+  if (counter && cfg->solver == T2FIT_SOLVER_LBFGSB) {
+    unsigned long long h[kCounterWords];
     T2_HIP(hipMemcpyAsync(h, counter, sizeof(h), hipMemcpyDeviceToHost, st));
     T2_HIP(hipStreamSynchronize(st));
-    const double tot = (double)(h[1] + h[2] + h[3]);
-    fprintf(stderr, "[t2fit stamps] refill %.1f%%  eval %.1f%%  advance %.1f%%  (wave-cycles %.3g)\n",
-            100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, tot);
-    if (h[4] + h[5] + h[6])
-      fprintf(stderr, "[t2fit stamps] advance: digest %.1f%%  build_b %.1f%%  cauchy %.1f%%  subsm %.1f%%  ls-setup %.1f%%  loop-glue %.1f%%  (of all wave-cycles)\n",
-              100.0 * h[4] / tot, 100.0 * h[5] / tot, 100.0 * h[6] / tot, 100.0 * h[7] / tot, 100.0 * h[8] / tot, 100.0 * h[9] / tot);
+    static const char* names[kDiagBlocks] = {"digest: ls tests", "digest: dcstep", "digest: new iterate", "begin: build_b",
+                                             "begin: cauchy", "begin: subsm", "begin: ls set-up", "eval", "refill",
+                                             "begin (all)", "wave life"};
+    const double life = (double)h[16 + 3 * 10];
+    for (int i = 0; i < kDiagBlocks; ++i) {
+      const unsigned long long* d = h + 16 + 3 * i;
+      fprintf(stderr, "[t2fit blocks] %-22s %6.2f%% of wave cycles, %5.1f lanes active, %10llu entries, %7.0f cycles each\n",
+              names[i], 100.0 * (double)d[0] / life, d[2] ? (double)d[1] / (double)d[2] : 0.0, d[2],
+              d[2] ? (double)d[0] / (double)d[2] : 0.0);
+    }
   }
 #endif
   if (counter) T2_HIP(hipFreeAsync(counter, st));

@@ -113,7 +113,7 @@ T2_HD float t2_sqrt(float x) { return sqrtf(x); }
 // exp: arguments here are -te/T2 or -2te/T2 with T2 >= the lower bound, never positive: the overflow select is
 // dead code, and ldexp() already delivers the denormal and zero results of the underflow select (checked against
 // the library down to -1.4e9; config_check keeps the argument above that).  sqrt: arguments are
-// k^2 E + sigma^2 in [0, 1e10]: the 2^-767 rescaling never triggers; zero is kept exact by one select.
+// k^2 E + sigma^2 in [0, 1e10]: the 2^-767 rescaling never triggers; zero stays exact (see below).
 #if defined(__HIP_DEVICE_COMPILE__)
 T2_HD double t2_exp_core(double x) {
   const double n = __builtin_rint(x * 0x1.71547652b82fep+0);
@@ -133,7 +133,10 @@ T2_HD double t2_exp_core(double x) {
   return __builtin_ldexp(p, (int)n);
 }
 T2_HD double t2_sqrt_core(double x) {
-  const double y = __builtin_amdgcn_rsq(x);
+  // rsq(0) = inf would turn the iteration into NaN; capped at 1e300 (far above rsq of any normal number, so
+  // nothing else changes) every step below yields an exact 0 for x = 0: one v_min instead of a compare and
+  // two selects behind each of the 32 square roots of an evaluation
+  const double y = fmin(__builtin_amdgcn_rsq(x), 1e300);
   double g = x * y, h = y * 0.5;
   const double r = fma(-h, g, 0.5);
   g = fma(g, r, g);
@@ -142,7 +145,7 @@ T2_HD double t2_sqrt_core(double x) {
   g = fma(d, h, g);
   d = fma(-g, g, x);
   g = fma(d, h, g);
-  return x == 0.0 ? x : g;
+  return g;
 }
 #else
 T2_HD double t2_exp_core(double x) { return exp(x); }
@@ -226,6 +229,9 @@ struct ObjCtx {
   double* trace = nullptr;  // optional: (k, T2, sigma, f) after each iteration, 4 doubles each
   int trace_cap = 0;
   int* trace_n = nullptr;
+#if defined(T2_PHASE_STAMPS)
+  unsigned long long* diag = nullptr;  // diagnostic build: this wave's block counters (t2fit_lbfgsb.h T2_BLK_END)
+#endif
   T2_HD float sample(int i) const { return y[i]; }
 };
 

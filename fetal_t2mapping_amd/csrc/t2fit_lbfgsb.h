@@ -23,6 +23,14 @@
 // of 3-vectors -- stays in registers.  Consequently the library's numerical-breakdown restarts
 // (Cholesky failure inside formk/formt) are replaced by a positive-definiteness check of the reduced
 // n x n system.  Everything is float64, as in the reference.
+//
+// Arithmetic contract (the library is compiled with -ffp-contract=off, so nothing is fused behind the source's back
+// and a restructured kernel gives the same bits): the objective (eval, objective_t) performs numpy's operations
+// one by one -- a product and the sum it feeds are two roundings, as in the reference -- and so do the parts that
+// restate library code statement by statement (projected gradient, the forward-difference quotient, dcsrch /
+// dcstep, the step bound and trial point of lnsrlb; scipy's wheels are built for baseline x86-64: no fused
+// multiply-add).  fma() is written out where this file has its own formulation anyway: the explicit-B recursion
+// and the Cauchy / subspace steps on it, and the correctly rounded quotient / exp / sqrt sequences of t2fit_lane.h.
 #pragma once
 
 #include <type_traits>
@@ -33,6 +41,26 @@
 #define T2_UNROLL _Pragma("unroll")
 #else
 #define T2_UNROLL
+#endif
+
+// Diagnostic build (-DT2_PHASE_STAMPS) only: wave-level cost of each block of the lane solver.  T2_BLK_END adds, for
+// block i, the shader cycles since the matching T2_BLK_T0, the number of lanes that were active in it and one
+// entry to three counters of the wave's own LDS block (c.diag); the kernel adds them up over the grid at exit.
+#if defined(T2_PHASE_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define T2_BLK_T0(name) const unsigned long long name = __builtin_amdgcn_s_memtime();
+#define T2_BLK_END(c, i, t0) t2_blk_end((c).diag, i, t0);
+__device__ __forceinline__ void t2_blk_end(unsigned long long* dg, int i, unsigned long long t0) {
+  const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
+  const unsigned long long ex = __ballot(true);
+  if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) {
+    dg[3 * i] += dt;
+    dg[3 * i + 1] += (unsigned long long)__popcll(ex);
+    dg[3 * i + 2] += 1ull;
+  }
+}
+#else
+#define T2_BLK_T0(name)
+#define T2_BLK_END(c, i, t0)
 #endif
 
 namespace t2fit {
@@ -114,7 +142,9 @@ T2_HD double t2_max3(double a, double b, double c) { return t2_max(a, t2_max(b, 
 // lanes of a wave usually sit in different cases, and four inlined copies of the divisions and the
 // square root would otherwise run one after the other.  Every value is formed by the same
 // operations, in the same order, as in the case-by-case form (3*(fp-fy)/(sty-stp) and
-// 3*(fy-fp)/(stp-sty) are the same floating-point number).
+// 3*(fy-fp)/(stp-sty) are the same floating-point number).  There is no branch in it: every choice is
+// a value select, so that the caller's other work (the new-iterate bookkeeping of the lanes whose line
+// search has ended) can be scheduled into the gaps of this long dependent chain.
 T2_HD void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy, double& dy, double& stp,
                   double fp, double dp, bool& brackt, double stpmin, double stpmax) {
   const double sgnd = !(dx < 0.0 || dx > 0.0) ? (double)NAN : (dx < 0.0 ? -dp : dp);  // dp * (dx / |dx|): the factor is exactly +-1
@@ -126,42 +156,38 @@ T2_HD void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy, 
   const double sta = c4 ? sty : stx, fa = c4 ? fy : fx, da = c4 ? dy : dx;
   const double theta = t2_fdiv(3.0 * (fa - fp), stp - sta) + da + dp;
   const double s = t2_max3(t2_abs(theta), t2_abs(da), t2_abs(dp));
-  const double ts = t2_fdiv(theta, s);
-  double arg = ts * ts - t2_fdiv(da, s) * t2_fdiv(dp, s);
-  if (c3) arg = t2_max(0.0, arg);
+  const double rs = t2_rcp_for_div(s);  // three quotients by s share its reciprocal
+  const double ts = t2_div_by_rcp(theta, s, rs);
+  double arg = ts * ts - t2_div_by_rcp(da, s, rs) * t2_div_by_rcp(dp, s, rs);
+  arg = c3 ? t2_max(0.0, arg) : arg;
   double gamma = s * t2_sqrt_core(arg);
   const bool flip = c1 ? stp < stx : (c4 ? stp > sty : stp > stx);
-  if (flip) gamma = -gamma;
+  gamma = flip ? -gamma : gamma;
   const double gd1 = c1 ? dx : dp;  // the slope subtracted from gamma
   const double p = (gamma - gd1) + theta;
   const double q = c3 ? (gamma + (dx - dp)) + gamma : ((gamma - gd1) + gamma) + (c1 ? dp : (c2 ? dx : dy));
   const double r = t2_fdiv(p, q);
+  const double far_end = stp > stx ? stpmax : stpmin;
   // cubic step
   double stpc = c1 ? stx + r * (stp - stx) : stp + r * (sta - stp);
-  if (c3 && !(r < 0.0 && gamma != 0.0)) stpc = stp > stx ? stpmax : stpmin;
-  // quadratic (case 1) or secant (cases 2, 3) step
-  const double quad = c1 ? t2_fdiv(dx, t2_fdiv(fx - fp, stp - stx) + dx) * 0.5 : t2_fdiv(dp, dp - dx);
+  stpc = (c3 && !(r < 0.0 && gamma != 0.0)) ? far_end : stpc;
+  // quadratic (case 1) or secant (cases 2, 3) step: one division chain on operands selected by case
+  //   case 1: ((dx / ((fx - fp) / (stp - stx) + dx)) / 2) ; otherwise dp / (dp - dx)
+  const double qden = c1 ? t2_fdiv(fx - fp, stp - stx) + dx : dp - dx;
+  const double qq = t2_fdiv(c1 ? dx : dp, qden);
+  const double quad = c1 ? qq * 0.5 : qq;
   const double stpq = c1 ? stx + quad * (stp - stx) : stp + quad * (stx - stp);
-  double stpf;
-  if (c1) {
-    stpf = t2_abs(stpc - stx) < t2_abs(stpq - stx) ? stpc : stpc + (stpq - stpc) * 0.5;
-  } else if (c2) {
-    stpf = t2_abs(stpc - stp) > t2_abs(stpq - stp) ? stpc : stpq;
-  } else if (c3) {
-    if (brackt) {
-      stpf = t2_abs(stpc - stp) < t2_abs(stpq - stp) ? stpc : stpq;
-      stpf = stp > stx ? t2_min(stp + 0.66 * (sty - stp), stpf) : t2_max(stp + 0.66 * (sty - stp), stpf);
-    } else {
-      stpf = t2_abs(stpc - stp) > t2_abs(stpq - stp) ? stpc : stpq;
-      stpf = t2_min(stpmax, stpf);
-      stpf = t2_max(stpmin, stpf);
-    }
-  } else {
-    stpf = brackt ? stpc : (stp > stx ? stpmax : stpmin);
-  }
-  if (c1 || c2) brackt = true;
-  // interval update, written as value selects (conditional stores through the reference
-  // parameters made the compiler keep the six values in scratch memory)
+  // the step taken
+  const double dc = t2_abs(stpc - stp), dq = t2_abs(stpq - stp);
+  const double f1 = t2_abs(stpc - stx) < t2_abs(stpq - stx) ? stpc : stpc + (stpq - stpc) * 0.5;
+  const double farther = dc > dq ? stpc : stpq, nearer = dc < dq ? stpc : stpq;
+  const double lim = stp + 0.66 * (sty - stp);
+  const double f3b = stp > stx ? t2_min(lim, nearer) : t2_max(lim, nearer);
+  const double f3u = t2_max(stpmin, t2_min(stpmax, farther));
+  const double f4 = brackt ? stpc : far_end;
+  const double stpf = c1 ? f1 : (c2 ? farther : (c3 ? (brackt ? f3b : f3u) : f4));
+  brackt = brackt || c1 || c2;
+  // interval update
   const bool swap = !c1 && sgnd < 0.0;
   const double nsty = c1 ? stp : (swap ? stx : sty);
   const double nfy = c1 ? fp : (swap ? fx : fy);
@@ -188,10 +214,12 @@ T2_HD void dcsrch_start(double f, double g, double stp, double ftol, double stpm
   s.task = LS_FG;
 }
 
-// Every later call: f, g are the objective and directional derivative at the trial step stp.
-T2_HD void dcsrch(double f, double g, double& stp, double gtol, double xtol, double stpmin, double stpmax,
-                  LsState& s) {
-  const double xtrapl = 1.1, xtrapu = 4.0, p5 = 0.5, p66 = 0.66;
+// Every later call: f, g are the objective and directional derivative at the trial step stp.  Two halves, so
+// that the caller can tell the cheap stop tests (every lane, every evaluation) from the safeguarded
+// step (only lanes whose search continues): dcsrch_tests() returns the task; if it is LS_FG,
+// dcsrch_update() computes the next trial step.
+T2_HD int dcsrch_tests(double f, double g, double stp, double gtol, double xtol, double stpmin, double stpmax,
+                       LsState& s) {
   const double ftest = s.finit + stp * s.gtest;
   if (s.stage == 1 && f <= ftest && g >= 0.0) s.stage = 2;
   int task = LS_FG;
@@ -200,44 +228,43 @@ T2_HD void dcsrch(double f, double g, double& stp, double gtol, double xtol, dou
   if (stp == stpmax && f <= ftest && g <= s.gtest) task = LS_WARN;      // stp = stpmax
   if (stp == stpmin && (f > ftest || g >= s.gtest)) task = LS_WARN;     // stp = stpmin
   if (f <= ftest && t2_abs(g) <= gtol * (-s.ginit)) task = LS_CONV;
-  if (task != LS_FG) { s.task = task; return; }
+  s.task = task;
+  return task;
+}
+
+T2_HD void dcsrch_update(double f, double g, double& stp, double xtol, double stpmin, double stpmax, LsState& s) {
+  const double xtrapl = 1.1, xtrapu = 4.0, p5 = 0.5, p66 = 0.66;
+  const double ftest = s.finit + stp * s.gtest;
   // stage 1 works on the modified function psi(stp) = f(stp) - f(0) - ftol*stp*f'(0)
   const bool modified = s.stage == 1 && f <= s.fx && f > ftest;
-  double fm = f, gm = g, fxm = s.fx, fym = s.fy, gxm = s.gx, gym = s.gy;
-  if (modified) {
-    fm = f - stp * s.gtest;
-    fxm = s.fx - s.stx * s.gtest;
-    fym = s.fy - s.sty * s.gtest;
-    gm = g - s.gtest;
-    gxm = s.gx - s.gtest;
-    gym = s.gy - s.gtest;
-  }
+  const double gt = modified ? s.gtest : 0.0;
+  double fm = modified ? f - stp * gt : f, gm = modified ? g - gt : g;
+  double fxm = modified ? s.fx - s.stx * gt : s.fx, fym = modified ? s.fy - s.sty * gt : s.fy;
+  double gxm = modified ? s.gx - gt : s.gx, gym = modified ? s.gy - gt : s.gy;
   dcstep(s.stx, fxm, gxm, s.sty, fym, gym, stp, fm, gm, s.brackt, s.stmin, s.stmax);
-  if (modified) {
-    s.fx = fxm + s.stx * s.gtest;
-    s.fy = fym + s.sty * s.gtest;
-    s.gx = gxm + s.gtest;
-    s.gy = gym + s.gtest;
-  } else {
-    s.fx = fxm; s.fy = fym; s.gx = gxm; s.gy = gym;
-  }
-  if (s.brackt) {
-    if (t2_abs(s.sty - s.stx) >= p66 * s.width1) stp = s.stx + p5 * (s.sty - s.stx);
-    s.width1 = s.width;
-    s.width = t2_abs(s.sty - s.stx);
-  }
-  if (s.brackt) {
-    s.stmin = t2_min(s.stx, s.sty);
-    s.stmax = t2_max(s.stx, s.sty);
-  } else {
-    s.stmin = stp + xtrapl * (stp - s.stx);
-    s.stmax = stp + xtrapu * (stp - s.stx);
-  }
+  s.fx = modified ? fxm + s.stx * gt : fxm;
+  s.fy = modified ? fym + s.sty * gt : fym;
+  s.gx = modified ? gxm + gt : gxm;
+  s.gy = modified ? gym + gt : gym;
+  const double span = t2_abs(s.sty - s.stx);
+  const double mid = s.stx + p5 * (s.sty - s.stx);
+  stp = (s.brackt && span >= p66 * s.width1) ? mid : stp;
+  s.width1 = s.brackt ? s.width : s.width1;
+  s.width = s.brackt ? span : s.width;
+  const double lo_b = t2_min(s.stx, s.sty), hi_b = t2_max(s.stx, s.sty);
+  const double lo_u = stp + xtrapl * (stp - s.stx), hi_u = stp + xtrapu * (stp - s.stx);
+  s.stmin = s.brackt ? lo_b : lo_u;
+  s.stmax = s.brackt ? hi_b : hi_u;
   stp = t2_max(stp, stpmin);
   stp = t2_min(stp, stpmax);
-  if ((s.brackt && (stp <= s.stmin || stp >= s.stmax)) || (s.brackt && s.stmax - s.stmin <= xtol * s.stmax))
-    stp = s.stx;
+  const bool stuck = s.brackt && ((stp <= s.stmin || stp >= s.stmax) || (s.stmax - s.stmin <= xtol * s.stmax));
+  stp = stuck ? s.stx : stp;
   s.task = LS_FG;
+}
+
+T2_HD void dcsrch(double f, double g, double& stp, double gtol, double xtol, double stpmin, double stpmax,
+                  LsState& s) {
+  if (dcsrch_tests(f, g, stp, gtol, xtol, stpmin, stpmax, s) == LS_FG) dcsrch_update(f, g, stp, xtol, stpmin, stpmax, s);
 }
 
 // numpy's float64 add.reduce order for a vector of n < 16 items, fed in index order with the index
@@ -268,7 +295,10 @@ struct NpSum {
 // runs the solver up to the next point it needs evaluated (or to the end).  A persistent kernel can
 // therefore keep the expensive eval() uniform across the lanes of a wave while every lane sits in a
 // different phase (or a different voxel) of its own fit.
-template <int MODEL>
+// NTE > 0 fixes the number of echoes at compile time (the kernels instantiate the common train lengths): the
+// evaluation then is one straight-line block -- no per-echo `i < n` tests between the echoes, so their
+// exp / sqrt chains interleave -- and only the summation order that numpy uses for that length is carried.
+template <int MODEL, int NTE = 0>
 struct Lbfgsb {
   static constexpr int N = MODEL == T2FIT_MODEL_GAUSSIAN ? 2 : 3;
   static constexpr int M = 10;
@@ -287,15 +317,12 @@ struct Lbfgsb {
   int col, nit, nfev, ifun;
   uint8_t status;
   bool first;
-#if defined(T2_PHASE_STAMPS)
-  unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0}, stamp_t = 0;  // diagnostic build: cycles per advance() block
-#endif
-#if defined(T2_PHASE_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
-#define T2_LSTAMP0() stamp_t = __builtin_amdgcn_s_memtime();
-#define T2_LSTAMP(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); stamp[i] += n_ - stamp_t; stamp_t = n_; }
+  bool wn_stale;  // the library's WN1 matrix would be out of date (see begin())
+#if !defined(__HIPCC__)
+  int n_reset = 0;  // host simulator only (debugging aid): how often the correction memory was dropped
+#define T2_COUNT_RESET() ++n_reset
 #else
-#define T2_LSTAMP0()
-#define T2_LSTAMP(i)
+#define T2_COUNT_RESET()
 #endif
 
   // scipy ScalarFunction.fun_and_grad with approx_derivative('2-point', abs_step=h, bounds): all N+1
@@ -304,7 +331,7 @@ struct Lbfgsb {
   // parallelism a lane needs at one wave per SIMD.
   T2_HD void eval(const ObjCtx& c) {
     const LaneParams& P = *c.P;
-    const int n = P.n_te;
+    const int n = NTE > 0 ? NTE : P.n_te;
     double x1[N], dx[N];
     T2_UNROLL
     for (int i = 0; i < N; ++i) {
@@ -429,10 +456,13 @@ struct Lbfgsb {
   // current one is applied, and the two scalings are reciprocals applied by multiplication: at one
   // wave per SIMD this block is latency-bound, and 18 IEEE divisions per pair dominated it.
   T2_HD void build_b(double (*B)[N]) const {
+    // the recursion carries the upper triangle only (U[i][j], j >= i): half the loop-carried registers and
+    // none of the mirror copies; the full matrix is written once, after the last pair
+    double U[N][N];
     T2_UNROLL
     for (int i = 0; i < N; ++i)
       T2_UNROLL
-      for (int j = 0; j < N; ++j) B[i][j] = i == j ? theta : 0.0;
+      for (int j = 0; j < N; ++j) U[i][j] = i == j ? theta : 0.0;
     double sp[N], yp[N];
     if (col > 0) {
       T2_UNROLL
@@ -449,11 +479,11 @@ struct Lbfgsb {
       for (int i = 0; i < N; ++i) {
         double a = 0.0;
         T2_UNROLL
-        for (int j = 0; j < N; ++j) a += B[i][j] * sp[j];
+        for (int j = 0; j < N; ++j) a = fma(j >= i ? U[i][j] : U[j][i], sp[j], a);
         bs[i] = a;
       }
       T2_UNROLL
-      for (int i = 0; i < N; ++i) { sbs += sp[i] * bs[i]; ys += yp[i] * sp[i]; }
+      for (int i = 0; i < N; ++i) { sbs = fma(sp[i], bs[i], sbs); ys = fma(yp[i], sp[i], ys); }
       const double rys = t2_fast_rcp(ys), rsbs = t2_fast_rcp(sbs);
       double ty[N], tb[N];
       T2_UNROLL
@@ -461,14 +491,14 @@ struct Lbfgsb {
       T2_UNROLL
       for (int i = 0; i < N; ++i)
         T2_UNROLL
-        for (int j = i; j < N; ++j) {
-          const double v = B[i][j] + (yp[i] * ty[j] - bs[i] * tb[j]);
-          B[i][j] = v;
-          B[j][i] = v;
-        }
+        for (int j = i; j < N; ++j) U[i][j] = fma(yp[i], ty[j], fma(-bs[i], tb[j], U[i][j]));
       T2_UNROLL
       for (int i = 0; i < N; ++i) { sp[i] = sn[i]; yp[i] = yn[i]; }
     }
+    T2_UNROLL
+    for (int i = 0; i < N; ++i)
+      T2_UNROLL
+      for (int j = 0; j < N; ++j) B[i][j] = j >= i ? U[i][j] : U[j][i];
   }
 
   // Generalized Cauchy point along the projected steepest-descent path.
@@ -496,7 +526,7 @@ struct Lbfgsb {
       d[i] = 0.0; tbk[i] = 0.0; zfix[i] = 0.0; hasbk[i] = false;
       if (iwhere[i] == 0) {
         d[i] = neggi;
-        f1 -= neggi * neggi;
+        f1 = fma(-neggi, neggi, f1);
         if (neggi != 0.0) {  // one division on the selected numerator instead of one per branch
           tbk[i] = t2_fdiv(neggi < 0.0 ? tl : tu, t2_abs(neggi));
           hasbk[i] = true;
@@ -511,7 +541,7 @@ struct Lbfgsb {
       T2_UNROLL
       for (int i = 0; i < N; ++i)
         T2_UNROLL
-        for (int j = 0; j < N; ++j) s += dd[i] * B[i][j] * dd[j];
+        for (int j = 0; j < N; ++j) s = fma(dd[i] * B[i][j], dd[j], s);
       return s;
     };
     double f2 = dBd(d);
@@ -562,8 +592,8 @@ struct Lbfgsb {
       for (int i = 0; i < N; ++i) {
         double bz = 0.0;
         T2_UNROLL
-        for (int j = 0; j < N; ++j) bz += B[i][j] * z[j];
-        f1 += d[i] * (g[i] + bz);
+        for (int j = 0; j < N; ++j) bz = fma(B[i][j], z[j], bz);
+        f1 = fma(d[i], g[i] + bz, f1);
       }
       f2 = t2_max(epsmch * f2_org, dBd(d));
       if (nleft > 0) dtm = t2_fdiv(-f1, f2);
@@ -573,7 +603,7 @@ struct Lbfgsb {
     dtm = t2_max(dtm, 0.0);
     tsum += dtm;
     T2_UNROLL
-    for (int i = 0; i < N; ++i) xcp[i] += tsum * d[i];
+    for (int i = 0; i < N; ++i) xcp[i] = fma(tsum, d[i], xcp[i]);
   }
 
   // Direct primal subspace minimisation over the variables free at the Cauchy point, followed by
@@ -589,7 +619,7 @@ struct Lbfgsb {
     for (int i = 0; i < N; ++i) {
       double bz = 0.0;
       T2_UNROLL
-      for (int j = 0; j < N; ++j) bz += B[i][j] * (z[j] - x[j]);
+      for (int j = 0; j < N; ++j) bz = fma(B[i][j], z[j] - x[j], bz);
       r[i] = fr[i] ? -(g[i] + bz) : 0.0;
     }
     // reduced system A du = r with A = B on free rows/cols, identity elsewhere; LDL^T, pivots must be > 0
@@ -604,13 +634,15 @@ struct Lbfgsb {
     const double d0 = A[0][0];
     if (!(d0 > 0.0)) return false;
     const double l10 = t2_fdiv(A[1][0], d0), l20 = t2_fdiv(A[2][0], d0);
-    const double d1 = A[1][1] - l10 * A[1][0];
+    const double d1 = fma(-l10, A[1][0], A[1][1]);
     if (!(d1 > 0.0)) return false;
-    const double l21 = t2_fdiv(A[2][1] - l20 * A[1][0], d1);
-    const double d2 = A[2][2] - l20 * A[2][0] - l21 * (A[2][1] - l20 * A[1][0]);
+    const double a21 = fma(-l20, A[1][0], A[2][1]);
+    const double l21 = t2_fdiv(a21, d1);
+    const double d2 = fma(-l21, a21, fma(-l20, A[2][0], A[2][2]));
     if (!(d2 > 0.0)) return false;
-    const double y0 = rr[0], y1 = rr[1] - l10 * y0, y2 = rr[2] - l20 * y0 - l21 * y1;
-    const double u2 = t2_fdiv(y2, d2), u1 = t2_fdiv(y1, d1) - l21 * u2, u0 = t2_fdiv(y0, d0) - l10 * u1 - l20 * u2;
+    const double y0 = rr[0], y1 = fma(-l10, y0, rr[1]), y2 = fma(-l21, y1, fma(-l20, y0, rr[2]));
+    const double u2 = t2_fdiv(y2, d2), u1 = fma(-l21, u2, t2_fdiv(y1, d1));
+    const double u0 = fma(-l20, u2, fma(-l10, u1, t2_fdiv(y0, d0)));
     du[0] = u0; du[1] = u1;
     if (N == 3) du[N - 1] = u2;
     // projected Newton point
@@ -628,7 +660,7 @@ struct Lbfgsb {
     if (!projected) return true;
     double ddp = 0.0;
     T2_UNROLL
-    for (int i = 0; i < N; ++i) ddp += (z[i] - x[i]) * g[i];
+    for (int i = 0; i < N; ++i) ddp = fma(z[i] - x[i], g[i], ddp);
     if (ddp > 0.0) {  // not a descent direction: backtrack along du from the Cauchy point instead
       T2_UNROLL
       for (int i = 0; i < N; ++i) z[i] = xp[i];
@@ -666,7 +698,7 @@ struct Lbfgsb {
       }
       T2_UNROLL
       for (int i = 0; i < N; ++i)
-        if (fr[i]) z[i] += alpha * du[i];
+        if (fr[i]) z[i] = fma(alpha, du[i], z[i]);
     }
     return true;
   }
@@ -688,76 +720,111 @@ struct Lbfgsb {
     theta = 1.0;
     status = T2FIT_ST_NOT_CONV;
     first = true;
+    wn_stale = false;
+    // digest() computes the line-search branches for every lane, also after the first evaluation of a fit, when
+    // there is no line search yet: give it defined values to chew on (its results are discarded there)
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) { z[i] = 0.0; d[i] = 0.0; t[i] = 0.0; r[i] = 0.0; g[i] = 0.0; }
+    f = 0.0; fold = 0.0; gd = 0.0; gdold = 0.0; stp = 1.0; stpmx = 1.0; sbgnrm = 0.0;
+    ls.task = LS_START; ls.stage = 1; ls.brackt = false;
+    ls.ginit = ls.gtest = ls.gx = ls.gy = ls.finit = ls.fx = ls.fy = 0.0;
+    ls.stx = ls.sty = ls.stmin = ls.stmax = ls.width = ls.width1 = 0.0;
   }
 
-  // Everything between two evaluations.  Control is arranged so that each expensive block (the
-  // end-of-iteration bookkeeping and the begin-iteration work: B, Cauchy point, subspace step,
-  // line-search set-up) exists exactly once in the instruction stream, so the lanes of a wave that
-  // sit in different phases serialise over little code.  Returns true when the fit has ended,
-  // false when `x` holds the next point to evaluate.
-  T2_HD bool advance(const ObjCtx& c) {
+  // Everything between two evaluations, in two halves.  digest() takes in the evaluation that just finished (line
+  // search stop tests; then either the next safeguarded trial step, or a new iterate: stop tests and the
+  // correction pair) and says what comes next; begin() (re)starts iterations -- B, Cauchy point, subspace step,
+  // line-search set-up -- until one yields a trial point or the fit ends.  Control is arranged so that each
+  // expensive block exists exactly once in the instruction stream, so the lanes of a wave that sit in different
+  // phases serialise over little code.  advance() = both: true when the fit has ended, false when `x` holds the
+  // next point to evaluate.
+  enum { GO_BEGIN, GO_TRIAL, GO_FAIL, GO_DONE };
+
+  T2_HD int digest(const ObjCtx& c) {
     const LaneParams& P = *c.P;
     const double epsmch = 2.220446049250313e-16;
-    enum { GO_BEGIN, GO_TRIAL, GO_FAIL, GO_DONE };
-    int next;
-    T2_LSTAMP0()
-    // ---- 1. digest the evaluation that just finished ----
-    if (first) {
-      first = false;
-      sbgnrm = projgr(x, g);
-      next = GO_BEGIN;
-      if (sbgnrm <= P.gtol) { status = T2FIT_ST_CONVERGED; next = GO_DONE; }
-    } else {
-      gd = 0.0;
-      T2_UNROLL
-      for (int i = 0; i < N; ++i) gd += g[i] * d[i];
-      dcsrch(f, gd, stp, 0.9, 0.1, 0.0, stpmx, ls);
-      if (ls.task == LS_FG) {
-        ++ifun;
-        next = ifun - 1 >= P.maxls ? GO_FAIL : GO_TRIAL;
-      } else {
-        // ---- new iterate: stop tests, then the correction pair ----
-        ++nit;
-        if (c.trace && *c.trace_n < c.trace_cap) {  // what scipy hands to the reference's callback (:180-234)
-          double* tr = c.trace + 4 * (*c.trace_n)++;
-          tr[0] = x[0]; tr[1] = x[1]; tr[2] = N == 3 ? x[N - 1] : 0.0; tr[3] = f;
-        }
-        sbgnrm = projgr(x, g);
-        const double tol = P.lbfgsb_tol;  // factr * epsmch = (ftol / epsmch) * epsmch, formed on the host
-        if (nit >= P.maxiter || nfev > P.maxfun) {
-          next = GO_DONE;  // scipy: STOP, success False
-        } else if (sbgnrm <= P.gtol || (fold - f) <= tol * t2_max3(t2_abs(fold), t2_abs(f), 1.0)) {
-          status = T2FIT_ST_CONVERGED;
-          next = GO_DONE;
-        } else {
-          double rr = 0.0, dr, ddum;
-          T2_UNROLL
-          for (int i = 0; i < N; ++i) { r[i] = g[i] - r[i]; rr += r[i] * r[i]; }
-          if (stp == 1.0) {
-            dr = gd - gdold;
-            ddum = -gdold;
-          } else {
-            dr = (gd - gdold) * stp;
-            T2_UNROLL
-            for (int i = 0; i < N; ++i) d[i] *= stp;
-            ddum = -gdold * stp;
-          }
-          if (!(dr <= epsmch * ddum)) {  // else: curvature too small, skip the update
-            if (col == M) {  // ring is full: the oldest pair is dropped
-              head = (head + 1) % M;
-              col = M - 1;
-            }
-            T2_UNROLL
-            for (int i = 0; i < N; ++i) { hs(col, i) = d[i]; hy(col, i) = r[i]; }
-            ++col;
-            theta = t2_fdiv(rr, dr);
-          }
-          next = GO_BEGIN;
-        }
+    // The lanes of a wave arrive here in three states: first evaluation of a fit, line search continues (the
+    // safeguarded step: a long chain of dependent divisions), line search ended (new iterate: stop tests and the
+    // correction pair).  At one wave per SIMD a dependent float64 chain issues at half rate, so the three are
+    // not branches: every lane computes all of them side by side in one block -- the compiler interleaves the
+    // independent chains -- and then keeps, by value selects, the results of the state it is in.  (Arithmetic on
+    // the state a lane is not in runs on stale or zero values and is thrown away; nothing here can trap.)
+    T2_BLK_T0(t_dig)
+    const bool was_first = first;
+    first = false;
+    // -- line search: directional derivative, stop tests --
+    double gdn = 0.0;
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) gdn += g[i] * d[i];
+    LsState lsn = ls;
+    const int task = dcsrch_tests(f, gdn, stp, 0.9, 0.1, 0.0, stpmx, lsn);
+    const bool cont = !was_first && task == LS_FG;   // line search continues
+    const bool newit = !was_first && task != LS_FG;  // a new iterate
+    // -- line search continues: next trial step --
+    double stpn = stp;
+    dcsrch_update(f, gdn, stpn, 0.1, 0.0, stpmx, lsn);
+    // -- new iterate (or first evaluation): projected gradient, stop tests, correction pair --
+    const double sb = projgr(x, g);
+    const double tol = P.lbfgsb_tol;  // factr * epsmch = (ftol / epsmch) * epsmch, formed on the host
+    const int nit1 = nit + 1;
+    const bool out_of_budget = nit1 >= P.maxiter || nfev > P.maxfun;  // scipy: STOP, success False
+    const bool converged = sb <= P.gtol || (!was_first && (fold - f) <= tol * t2_max3(t2_abs(fold), t2_abs(f), 1.0));
+    double rn[N], dn[N], rr = 0.0;
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) { rn[i] = g[i] - r[i]; rr += rn[i] * rn[i]; }
+    // (the library scales by stp only when stp != 1; multiplying by 1.0 is exact, so no test is needed)
+    const double dr = (gdn - gdold) * stp, ddum = -gdold * stp;
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) dn[i] = d[i] * stp;
+    const double theta_n = t2_fdiv(rr, dr);
+    const bool iterate_on = newit && !out_of_budget && !converged;
+    const bool store_pair = iterate_on && !(dr <= epsmch * ddum);  // else: curvature too small, skip the update
+    // -- keep what belongs to this lane's state --
+    if (!was_first) gd = gdn;
+    if (cont) { ls = lsn; stp = stpn; ++ifun; }
+    if (!cont && !was_first) ls.task = lsn.task;
+    if (was_first || newit) sbgnrm = sb;
+    if (newit) {
+      nit = nit1;
+      if (c.trace && *c.trace_n < c.trace_cap) {  // what scipy hands to the reference's callback (:180-234)
+        double* tr = c.trace + 4 * (*c.trace_n)++;
+        tr[0] = x[0]; tr[1] = x[1]; tr[2] = N == 3 ? x[N - 1] : 0.0; tr[3] = f;
       }
     }
-    T2_LSTAMP(0)
-    // ---- 2. (re)start iterations until one yields a trial point or the fit ends ----
+    if (iterate_on) {
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) { r[i] = rn[i]; d[i] = dn[i]; }
+    }
+    if (store_pair) {
+      if (col == M) {  // ring is full: the oldest pair is dropped
+        head = (head + 1) % M;
+        col = M - 1;
+      }
+      T2_UNROLL
+      for (int i = 0; i < N; ++i) { hs(col, i) = dn[i]; hy(col, i) = rn[i]; }
+      ++col;
+      theta = theta_n;
+    }
+    if ((was_first || newit) && converged && !(newit && out_of_budget)) status = T2FIT_ST_CONVERGED;
+    int next;
+    if (cont) next = ifun - 1 >= P.maxls ? GO_FAIL : GO_TRIAL;
+    else if (was_first) next = converged ? GO_DONE : GO_BEGIN;
+    else next = (out_of_budget || converged) ? GO_DONE : GO_BEGIN;
+    T2_BLK_END(c, 0, t_dig)
+    if (next == GO_TRIAL) set_trial();
+    return next;
+  }
+
+  // x = the trial point of the running line search
+  T2_HD void set_trial() {
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) x[i] = stp == 1.0 ? z[i] : stp * d[i] + t[i];
+  }
+
+  // `next` is GO_BEGIN or GO_FAIL (what digest() returned).  Returns true when the fit has ended, false when `x`
+  // holds the next point to evaluate.
+  T2_HD bool begin(const ObjCtx& c, int next) {
+    const LaneParams& P = *c.P;
     for (;;) {
       if (next == GO_FAIL) {
         // line search could not be completed: back to the previous iterate.  With an empty memory
@@ -766,25 +833,47 @@ struct Lbfgsb {
         for (int i = 0; i < N; ++i) { x[i] = t[i]; g[i] = r[i]; }
         f = fold;
         next = GO_DONE;
-        if (col != 0) { col = 0; theta = 1.0; next = GO_BEGIN; }
+        if (col != 0) { col = 0; theta = 1.0; wn_stale = false; next = GO_BEGIN; T2_COUNT_RESET(); }
       }
       if (next != GO_BEGIN) break;
       double B[N][N];
-      T2_LSTAMP(5)
+      T2_BLK_T0(t_b)
       build_b(B);
-      T2_LSTAMP(1)
+      T2_BLK_END(c, 3, t_b)
+      T2_BLK_T0(t_c)
       cauchy(x, g, B, theta, sbgnrm, iwhere, z);
-      T2_LSTAMP(2)
+      T2_BLK_END(c, 4, t_c)
       int nfree = 0;
       T2_UNROLL
       for (int i = 0; i < N; ++i) nfree += iwhere[i] <= 0;
       if (nfree != 0 && col != 0) {
-        if (!subsm(x, g, B, iwhere, z)) {  // numerical breakdown: drop the memory, redo the iteration
+        if (wn_stale) {
+          // The library keeps its 2m x 2m matrix WN1 (inner products of the pairs over the free and the active
+          // variables) up to date inside formk, which it only calls when a subspace step is taken.  An iteration
+          // whose Cauchy point leaves no variable free skips formk, so the changes of that iteration (the newest
+          // pair, the variables that left the free set) never reach WN1; at the next iteration that takes a
+          // subspace step the factorisation of the then inconsistent matrix fails ("nonpositive definiteness in
+          // Cholesky factorization in formk") and the library drops its memory and restarts the iteration.  This
+          // is deterministic and frequent when bounds are active (5-8 % of the voxels of a --no_prior fit; all
+          // 150 restarts the reference makes on the golden fixtures follow this rule, none is missed by it), so it
+          // is part of the reference's trajectory and is restated here, without the matrix: a flag.
+          wn_stale = false;
           col = 0; theta = 1.0;
+          T2_COUNT_RESET();
           continue;
         }
+        T2_BLK_T0(t_s)
+        const bool ok = subsm(x, g, B, iwhere, z);
+        T2_BLK_END(c, 5, t_s)
+        if (!ok) {  // numerical breakdown: drop the memory, redo the iteration
+          col = 0; theta = 1.0;
+          T2_COUNT_RESET();
+          continue;
+        }
+      } else if (col != 0) {
+        wn_stale = true;  // no variable is free at the Cauchy point: the library skips formk (see above)
       }
-      T2_LSTAMP(3)
+      T2_BLK_T0(t_l)
       // line search along d = z - x (lnsrlb)
       T2_UNROLL
       for (int i = 0; i < N; ++i) { d[i] = z[i] - x[i]; t[i] = x[i]; r[i] = g[i]; }
@@ -813,15 +902,20 @@ struct Lbfgsb {
       dcsrch_start(f, gd, stp, 1e-3, 0.0, stpmx, ls);  // ERROR also covers gd >= 0: not a descent direction
       ifun = 1;
       next = (ls.task != LS_FG || ifun - 1 >= P.maxls) ? GO_FAIL : GO_TRIAL;
-      T2_LSTAMP(4)
+      T2_BLK_END(c, 6, t_l)
     }
-    T2_LSTAMP(5)
     if (next == GO_TRIAL) {
-      T2_UNROLL
-      for (int i = 0; i < N; ++i) x[i] = stp == 1.0 ? z[i] : stp * d[i] + t[i];
+      set_trial();
       return false;
     }
     return true;
+  }
+
+  T2_HD bool advance(const ObjCtx& c) {
+    const int next = digest(c);
+    if (next == GO_TRIAL) return false;
+    if (next == GO_DONE) return true;
+    return begin(c, next);
   }
 
   T2_HD void result(LaneResult& out) const {

@@ -14,6 +14,12 @@
 
 #include "t2fit_lane.h"
 
+// This solver is this library's own formulation, not a restatement of reference arithmetic: multiply-adds may fuse
+// (the library as a whole is compiled with -ffp-contract=off, see t2fit_lbfgsb.h).
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+
 namespace t2fit {
 
 template <typename T> struct LmEval {
@@ -323,3 +329,7 @@ T2_HD void lm_solve(const ObjCtx& c, const double* lbd, const double* ubd, LaneR
 }
 
 }  // namespace t2fit
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif

@@ -15,6 +15,12 @@
 
 #include "t2fit_lane.h"
 
+// This solver is this library's own formulation, not a restatement of reference arithmetic: multiply-adds may fuse
+// (the library as a whole is compiled with -ffp-contract=off, see t2fit_lbfgsb.h).
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+
 namespace t2fit {
 
 T2_HD float t2_logf_precise(float x) { return logf(x); }  // the ~1 ulp library form, not v_log_f32 alone
@@ -93,3 +99,7 @@ T2_HD void loglin_solve(const ObjCtx& c, const double* lb, const double* ub, boo
 }
 
 }  // namespace t2fit
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif

@@ -13,6 +13,12 @@ compared with the unperturbed golden answers.  No implementation that is not bit
 reference's own binary stack can be expected to agree with the golden vectors better than this,
 so tests/test_gpu_parity.py requires the HIP lane solver to reach the same agreement.
 
+K_SEEDS independent perturbations are run per fixture.  They also define the fixture's STABLE set: the voxels on
+which every perturbed run reproduces the golden result (same iteration count, same success flag, T2 within
+1e-3 ms).  On those voxels the reference's answer does not depend on the last bit of exp(), so there an
+implementation has no excuse: tests/test_gpu_parity.py::test_lbfgsb_stable_set demands T2 within 1 ms and equal
+nit / success on (all but one in a thousand of) them.
+
     cd /root/repo && OPENBLAS_NUM_THREADS=1 python -B tests/golden/make_noise_floor.py
 """
 import glob
@@ -26,66 +32,82 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import numpy as np  # noqa: E402
 import scipy  # noqa: E402
 from scipy.optimize import minimize  # noqa: E402
-from scipy.special import i0e  # noqa: E402
 
 from oracle import t2fit_oracle as O  # noqa: E402
+from oracle.noise_model import perturbed_objectives  # noqa: E402
 
-EPS = np.finfo(float).eps
 
 
-def perturbed_objectives(rng):
-    def pexp(z):
-        e = np.exp(z)
-        return e * (1 + EPS * rng.integers(-1, 2, size=np.shape(e)))
+K_SEEDS = 24  # perturbation seeds per fixture; the STABLE set of a fixture = voxels on which every one of them stays put
 
-    def gauss(p, te, y):
-        k, t2 = p
-        r = y - k * pexp(-te / t2)
-        return np.sum(r ** 2) / len(y)
 
-    def gauss_rician(p, te, y):
-        k, t2, s = p
-        r = y - (k ** 2 * pexp(-2 * te / t2) + s ** 2) ** (1 / 2)
-        return np.sum(r ** 2) / len(y)
-
-    def rician(p, te, y):
-        k, t2, s = p
-        m = k * pexp(-te / t2)
-        x = (m * y) / (s ** 2)
-        return -np.sum((np.log(y) - np.log(s ** 2)) - (y ** 2 + m ** 2) / (2 * s ** 2) + (np.abs(x) + np.log(i0e(x))))
-
-    return {"gaussian": gauss, "gaussian_rician": gauss_rician, "rician": rician}
+def one_run(args):
+    """The reference's fit of every fittable row of one fixture with every exp() moved by at most one ulp (seed)."""
+    path, seed = args
+    d = np.load(path)
+    mode, lf, prior = str(d["mode"]), bool(d["low_field"]), bool(d["prior"])
+    fun = perturbed_objectives(np.random.default_rng(seed))[mode]
+    m = d["y"].shape[0]
+    x = np.full((m, d["x"].shape[1]), np.nan)
+    nit = np.zeros(m, np.int32)
+    ok = np.zeros(m, bool)
+    for v in range(m):
+        if d["raised"][v] or not np.all(np.isfinite(d["y"][v])):
+            continue
+        fp = O.fit_table(mode, lf)
+        lb, ub = O.voxel_bounds(fp, d["y"][v, 0], prior)
+        with np.errstate(all="ignore"):
+            r = minimize(fun, fp["initial_guess"], args=(d["te"], np.array(d["y"][v])), method="L-BFGS-B",
+                         bounds=list(zip(lb, ub)), options=fp["options"], jac=False)
+        x[v], nit[v], ok[v] = r.x, r.nit, r.success
+    return x, nit, ok
 
 
 def main():
+    import multiprocessing as mp
+
     out = {}
-    for path in sorted(glob.glob(os.path.join(HERE, "voxels_*.npz"))):
+    paths = sorted(glob.glob(os.path.join(HERE, "voxels_*.npz")))
+    seeds = [12345 + 1000 * j for j in range(K_SEEDS)]  # seed 0 is round 1's
+    with mp.get_context("fork").Pool(min(8, os.cpu_count() or 1)) as pool:
+        runs = pool.map(one_run, [(p, sd) for p in paths for sd in seeds], chunksize=1)
+    for pi, path in enumerate(paths):
         d = np.load(path)
         name = os.path.basename(path)[7:-4]
-        mode, lf, prior = str(d["mode"]), bool(d["low_field"]), bool(d["prior"])
-        fun = perturbed_objectives(np.random.default_rng(12345))[mode]
-        m = d["y"].shape[0]
-        x = np.full((m, d["x"].shape[1]), np.nan)
-        nit = np.zeros(m, np.int32)
-        ok = np.zeros(m, bool)
-        for v in range(m):
-            if d["raised"][v] or not np.all(np.isfinite(d["y"][v])):
-                continue
-            fp = O.fit_table(mode, lf)
-            lb, ub = O.voxel_bounds(fp, d["y"][v, 0], prior)
-            with np.errstate(all="ignore"):
-                r = minimize(fun, fp["initial_guess"], args=(d["te"], np.array(d["y"][v])), method="L-BFGS-B",
-                             bounds=list(zip(lb, ub)), options=fp["options"], jac=False)
-            x[v], nit[v], ok[v] = r.x, r.nit, r.success
-        good = np.isfinite(x[:, 1]) & np.isfinite(d["x"][:, 1])
-        dt = np.abs(x[good, 1] - d["x"][good, 1])
-        out[name + "/x"] = x
-        out[name + "/nit"] = nit
-        out[name + "/frac_1ms"] = np.float64(np.mean(dt <= 1.0))
-        out[name + "/median_dt2"] = np.float64(np.median(dt))
-        out[name + "/nit_equal"] = np.float64(np.mean(nit[good] == d["nit"][good]))
-        print(f"{name:38s} within 1 ms {out[name + '/frac_1ms']:.3f}  median |dT2| {out[name + '/median_dt2']:.2g} ms  "
-              f"nit equal {out[name + '/nit_equal']:.3f}", flush=True)
+        mine = runs[pi * K_SEEDS:(pi + 1) * K_SEEDS]
+        good = np.isfinite(d["x"][:, 1]) & np.isfinite(d["fun"]) & ~d["raised"]
+        fr, ne = [], []
+        strict_fail = np.zeros(len(good), np.uint32)  # bit j: seed j does not reproduce the golden row exactly enough
+        loose_fail = np.zeros(len(good), np.uint32)   # bit j: seed j ends more than 1 ms away in T2
+        nit_fail = np.zeros(len(good), np.uint32)     # bit j: seed j takes another number of iterations
+        for j, (x, nit, ok) in enumerate(mine):
+            dt = np.abs(x[:, 1] - d["x"][:, 1])
+            fr.append(np.mean(dt[good] <= 1.0))
+            ne.append(np.mean(nit[good] == d["nit"][good]))
+            # stays put: same iteration count, same success flag, T2 within 1e-3 ms
+            strict_ok = np.isfinite(x[:, 1]) & (dt <= 1e-3) & (nit == d["nit"]) & (ok == d["success"])
+            strict_fail |= np.where(strict_ok, 0, 1 << j).astype(np.uint32)
+            loose_fail |= np.where(np.isfinite(x[:, 1]) & (dt <= 1.0), 0, 1 << j).astype(np.uint32)
+            nit_fail |= np.where(nit == d["nit"], 0, 1 << j).astype(np.uint32)
+        stable = good & (strict_fail == 0)
+        x0, nit0, _ = mine[0]
+        dt0 = np.abs(x0[good, 1] - d["x"][good, 1])
+        out[name + "/x"] = x0
+        out[name + "/nit"] = nit0
+        out[name + "/frac_1ms"] = np.float64(np.mean(fr))          # mean over the seeds
+        out[name + "/frac_1ms_min"] = np.float64(np.min(fr))
+        out[name + "/frac_1ms_seeds"] = np.array(fr)
+        out[name + "/median_dt2"] = np.float64(np.median(dt0))
+        out[name + "/nit_equal"] = np.float64(np.mean(ne))
+        out[name + "/nit_equal_min"] = np.float64(np.min(ne))
+        out[name + "/stable"] = stable
+        out[name + "/good"] = good
+        out[name + "/strict_fail_bits"] = strict_fail
+        out[name + "/loose_fail_bits"] = loose_fail
+        out[name + "/nit_fail_bits"] = nit_fail
+        print(f"{name:38s} within 1 ms: mean {np.mean(fr):.3f} min {np.min(fr):.3f}  nit equal {np.mean(ne):.3f}  "
+              f"stable {int(stable.sum())}/{int(good.sum())}", flush=True)
+    out["k_seeds"] = np.int64(K_SEEDS)
     out["numpy_version"] = np.array(np.__version__)
     out["scipy_version"] = np.array(scipy.__version__)
     np.savez_compressed(os.path.join(HERE, "noise_floor.npz"), **out)

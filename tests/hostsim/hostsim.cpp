@@ -103,3 +103,38 @@ extern "C" int hostsim_residuals(const t2fit_config* cfg, const float* rows, int
   }
   return 0;
 }
+
+// every point the reference-trajectory lane solver evaluates (line-search trials included), with f and the
+// forward-difference gradient: pts[7 * i] = x0, x1, x2, f, g0, g1, g2.  Debugging aid for comparing the lane solver's
+// control flow with scipy's step by step.
+extern "C" int hostsim_eval_points(const t2fit_config* cfg, const float* row, double* pts, int cap, int* n_out) {
+  const char* why;
+  int rc = config_check(cfg, &why);
+  if (rc != T2FIT_OK) return rc;
+  const LaneParams P = make_lane_params(*cfg);
+  float buf[T2FIT_MAX_TE];
+  for (int i = 0; i < cfg->n_te; ++i) buf[i] = row[i];
+  bool finite;
+  float y0_raw;
+  ObjCtx c = prepare_samples(P, buf, 1, finite, y0_raw);
+  double lb[3], ub[3];
+  if (!lane_bounds(P, y0_raw, lb, ub) || !finite) return -10;
+  *n_out = 0;
+  auto run = [&](auto& s) {
+    double hist[60];
+    s.init(P.x0, lb, ub, hist, 1);
+    do {
+      s.eval(c);
+      if (*n_out < cap) {
+        double* p = pts + 7 * (*n_out)++;
+        for (int j = 0; j < 3; ++j) { p[j] = j < s.N ? s.x[j] : 0.0; p[4 + j] = j < s.N ? s.g[j] : 0.0; }
+        p[3] = s.f;
+      }
+    } while (!s.advance(c));
+    if (*n_out < cap) pts[7 * (*n_out)] = (double)s.n_reset;  // one slot past the last point: memory resets
+  };
+  if (P.model == T2FIT_MODEL_GAUSSIAN) { Lbfgsb<T2FIT_MODEL_GAUSSIAN> s; run(s); }
+  else if (P.model == T2FIT_MODEL_GAUSSIAN_RICIAN) { Lbfgsb<T2FIT_MODEL_GAUSSIAN_RICIAN> s; run(s); }
+  else { Lbfgsb<T2FIT_MODEL_RICIAN> s; run(s); }
+  return 0;
+}

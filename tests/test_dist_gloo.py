@@ -43,6 +43,25 @@ def _worker(rank, world, port, n_vox, n_te, out):
     dist.destroy_process_group()
 
 
+def _worker_cyclic(rank, world, port, n_vox, n_te, chunk, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(6)
+    echoes = rng.normal(size=(n_te, n_vox)).astype(np.float32)
+    mask = (rng.random(n_vox) < 0.6).astype(np.uint8)
+    e, m = t2dist.take_cyclic(echoes, mask, rank, world, chunk)
+    per = t2dist.cyclic_len(n_vox, world, chunk)
+    assert e.shape == (n_te, per) and m.shape == (per,)
+    idx = t2dist.cyclic_index(n_vox, rank, world, chunk)  # the documented slot -> voxel map
+    real = idx >= 0
+    assert np.array_equal(e[:, real], echoes[:, idx[real]]) and np.array_equal(m[real], mask[idx[real]]) and not m[~real].any()
+    packed = torch.from_numpy(_fake_fit(e, m))
+    full = t2dist.gather_maps_cyclic(packed, n_vox, chunk).numpy()
+    out[rank] = bool(np.array_equal(full, _fake_fit(echoes, mask)))
+    dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -57,6 +76,35 @@ def test_slab_partition_and_allgather(world, n_vox):
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), n_vox, 4, out), nprocs=world, join=True)
     assert all(out[r] for r in range(world)) and len(out) == world
+
+
+@pytest.mark.parametrize("world,n_vox,chunk", [(2, 1000, 64), (2, 1001, 64), (3, 10, 4), (2, 1, 16), (3, 5000, 256)])
+def test_cyclic_partition_and_allgather(world, n_vox, chunk):
+    """Chunks dealt round-robin (the balanced partition of one volume): share of each rank, padding, one
+    all_gather_into_tensor and the strided view back into voxel order reproduce the whole volume bit for bit."""
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_cyclic, args=(world, _free_port(), n_vox, 4, chunk, out), nprocs=world, join=True)
+    assert all(out[r] for r in range(world)) and len(out) == world
+
+
+def test_cyclic_partition_covers_every_voxel_once_and_balances_an_ellipsoid():
+    for n, g, chunk in ((0, 2, 8), (1, 8, 8), (1000, 3, 16), (256 * 256 * 32, 8, t2dist.CHUNK)):
+        idx = np.concatenate([t2dist.cyclic_index(n, r, g, chunk) for r in range(g)])
+        assert np.array_equal(np.sort(idx[idx >= 0]), np.arange(n))
+        assert len(idx) == g * t2dist.cyclic_len(n, g, chunk)
+    # the reason the partition exists: masked voxels per rank on an ellipsoidal mask, 8 ranks
+    from fetal_t2mapping_amd import synth
+
+    _, mask, _ = synth.brain_volume((64, 64, 64), 2, seed=1)
+    flat = mask.reshape(-1)
+    per_slab = [int(flat[slice(*t2dist.slab_range(flat.size, r, 8))].sum()) for r in range(8)]
+    per_cyc = []
+    for r in range(8):
+        idx = t2dist.cyclic_index(flat.size, r, 8, 1024)
+        per_cyc.append(int(flat[idx[idx >= 0]].sum()))
+    assert max(per_slab) / np.mean(per_slab) > 1.4      # contiguous slabs: the middle ranks do 1.5x the average work
+    assert max(per_cyc) / np.mean(per_cyc) < 1.08       # cyclic chunks: within a few percent
 
 
 def test_slab_ranges_cover_the_volume():

@@ -266,12 +266,13 @@ def _floor():
 
 @pytest.mark.parametrize("path", FILES, ids=_ids(FILES))
 def test_lbfgsb_matches_reference(t2, path):
-    """T2 within 1 ms of the reference's scipy result (north_star tolerance).
+    """T2 within 1 ms of the reference's scipy result (north_star tolerance), every fixture.
 
-    The reference's answer is chaotic in the last bit of exp() (forward differences with h = 1e-8,
-    loose stops; tests/golden/make_noise_floor.py), so the bar per configuration is the agreement
-    the reference reaches with ITSELF under a one-ulp perturbation of exp(), minus 4 points of
-    binomial slack for ~250 voxels; configurations whose floor is 100 % must reach 99 %.
+    The reference's answer is chaotic in the last bit of exp() (forward differences with h = 1e-8, loose stops;
+    oracle/noise_model.py), so the bar per fixture is the agreement the reference reaches with ITSELF under a one-ulp
+    perturbation of its library functions: HIP must be within 1 point of the WORST of the reference's 24 perturbed
+    runs (tests/golden/noise_floor.npz), in the fraction of voxels within 1 ms and in the fraction with the same
+    iteration count.  (test_lbfgsb_stable_set is the sharp test; this one covers every voxel.)
     """
     from fetal_t2mapping_amd import _abi
 
@@ -288,15 +289,48 @@ def test_lbfgsb_matches_reference(t2, path):
     fit = good & np.isfinite(d["fun"])
     dt = np.abs(x[fit, 1] - d["x"][fit, 1])
     frac = float(np.mean(dt <= T2_TOL_MS))
-    floor = float(_floor()[name + "/frac_1ms"])
-    assert frac >= min(0.99, floor - 0.04), (name, frac, floor)
+    nf = _floor()
+    assert frac >= float(nf[name + "/frac_1ms_min"]) - 0.01, (name, frac, float(nf[name + "/frac_1ms_min"]))
     assert np.median(dt) <= 0.02
-    assert np.mean(ok[fit] == d["success"][fit]) >= 0.99
-    assert np.mean(nit[fit] == d["nit"][fit]) >= float(_floor()[name + "/nit_equal"]) - 0.12
+    assert np.mean(ok[fit] == d["success"][fit]) >= 0.995
+    assert np.mean(nit[fit] == d["nit"][fit]) >= float(nf[name + "/nit_equal_min"]) - 0.01
     # where T2 agrees, k (S0) agrees too; sigma is left out: it is poorly determined at these stops
     agree = dt <= T2_TOL_MS
     rel_k = np.abs(x[fit][agree, 0] - d["x"][fit][agree, 0]) / np.abs(d["x"][fit][agree, 0])
     assert np.percentile(rel_k, 95) <= REL_TOL
+
+
+@pytest.mark.parametrize("model", ["gaussian", "gaussian_rician", "rician"])
+def test_lbfgsb_stable_set(t2, model):
+    """Parity where the reference is well defined.  The STABLE set of a fixture (tests/golden/make_noise_floor.py)
+    holds the voxels on which all 24 one-ulp-perturbed runs of the reference reproduce the golden row: same iteration
+    count, same success flag, T2 within 1e-3 ms.  There the answer does not hang on the last bit of a library
+    function, so an implementation that walks the reference's trajectory must reproduce it too: over the twelve
+    fixtures of a model (about a thousand stable voxels) T2 within 1 ms on >= 99.9 %, `success` equal on all,
+    `nit` equal on >= 99.5 % (the reference's own leave-one-seed-out rate of a changed iteration count on these
+    voxels is 0.3 % for the 2-parameter model), and no fixture with more than one voxel off.
+
+    This is the test that found the library's stale-WN1 restarts (t2fit_lbfgsb.h begin()): without them the lane
+    solver left the trajectory on 5 of 3105 stable voxels."""
+    nf = _floor()
+    n_stable = n_t2 = n_nit = n_ok = 0
+    for path in [f for f in FILES if os.path.basename(f)[10:].startswith(model + "_prior") or
+                 os.path.basename(f)[10:].startswith(model + "_noprior")]:
+        d = np.load(path)
+        name = os.path.basename(path)[7:-4]
+        stable = nf[name + "/stable"]
+        rows = np.flatnonzero(stable)
+        x, ok, nit, fun, st = t2.fit_voxels(rows, model, _table(t2, d), d["te"], d["y"], bool(d["prior"]), False)
+        off = np.abs(x[:, 1] - d["x"][rows, 1]) > T2_TOL_MS
+        assert off.sum() <= 1, (name, rows[off])
+        n_stable += len(rows)
+        n_t2 += int(off.sum())
+        n_nit += int(np.sum(nit != d["nit"][rows]))
+        n_ok += int(np.sum(ok != d["success"][rows]))
+    assert n_stable >= 700, n_stable
+    assert n_ok == 0
+    assert n_t2 <= 1e-3 * n_stable, (n_t2, n_stable)
+    assert n_nit <= 5e-3 * n_stable, (n_nit, n_stable)
 
 
 def test_lbfgsb_volume_matches_reference_volume(t2):

@@ -18,6 +18,8 @@ PICK = [f for f in FILES if os.path.basename(f)[7:-4] in (
 
 @pytest.mark.parametrize("path", PICK, ids=lambda p: os.path.basename(p)[7:-4])
 def test_lbfgsb_lane_solver_tracks_reference(path):
+    """Every voxel of a fixture: at least as close to the reference as the worst of the reference's own 24 one-ulp
+    perturbed runs, less one point (tests/golden/make_noise_floor.py), in T2 and in the iteration count."""
     d = np.load(path)
     floor = np.load(os.path.join(GOLDEN, "noise_floor.npz"))
     name = os.path.basename(path)[7:-4]
@@ -26,12 +28,34 @@ def test_lbfgsb_lane_solver_tracks_reference(path):
     assert np.array_equal(o["status"] == 4, d["raised"])
     fit = ~d["raised"] & np.isfinite(d["fun"])
     dt = np.abs(o["x"][fit, 1] - d["x"][fit, 1])
-    assert np.mean(dt <= 1.0) >= min(0.99, float(floor[name + "/frac_1ms"]) - 0.04)
+    assert np.mean(dt <= 1.0) >= float(floor[name + "/frac_1ms_min"]) - 0.01
+    assert np.mean(o["nit"][fit] == d["nit"][fit]) >= float(floor[name + "/nit_equal_min"]) - 0.01
     assert np.median(dt) <= 0.02
-    assert np.mean((o["status"][fit] == 1) == d["success"][fit]) >= 0.99
+    assert np.mean((o["status"][fit] == 1) == d["success"][fit]) >= 0.995
     bad = ~d["raised"] & ~np.isfinite(d["fun"])
     n_par = d["x"].shape[1]
     assert np.allclose(o["x"][bad][:, :n_par], d["x"][bad]) and np.all(o["nit"][bad] == 0)
+
+
+def test_lbfgsb_lane_solver_on_the_stable_sets():
+    """Where the reference's answer does not depend on the last bit of exp() / log() / i0e() -- the stable set of each
+    fixture: all 24 perturbed runs of the reference reproduce the golden row -- the lane solver must reproduce it
+    too: over all 36 fixtures (3105 voxels) T2 within 1 ms on >= 99.9 %, `success` equal on all, `nit` equal on
+    >= 99.5 %.  (The HIP path is held to the same bar on the GPU: test_gpu_parity.py::test_lbfgsb_stable_set.)"""
+    floor = np.load(os.path.join(GOLDEN, "noise_floor.npz"))
+    n = n_t2 = n_nit = n_ok = 0
+    for path in FILES:
+        d = np.load(path)
+        name = os.path.basename(path)[7:-4]
+        rows = np.flatnonzero(floor[name + "/stable"])
+        cfg = sim.config(str(d["mode"]), bool(d["low_field"]), d["te"], prior=bool(d["prior"]), solver="lbfgsb")
+        o = sim.fit_rows(cfg, d["y"][rows])
+        n += len(rows)
+        n_t2 += int(np.sum(np.abs(o["x"][:, 1] - d["x"][rows, 1]) > 1.0))
+        n_nit += int(np.sum(o["nit"] != d["nit"][rows]))
+        n_ok += int(np.sum((o["status"] == 1) != d["success"][rows]))
+    assert n >= 3000
+    assert n_ok == 0 and n_t2 <= 1e-3 * n and n_nit <= 5e-3 * n, (n, n_t2, n_nit, n_ok)
 
 
 @pytest.mark.parametrize("path", [f for f in FILES if "gaussian_prior_te6" in f or "gaussian_rician_prior_te3" in f],
