@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Mvoxel/s of the per-voxel T2 fit on synthetic 256^3 x 8 TE volumes.
+"""Headline benchmark: Mvoxel/s of the per-voxel T2 fit on a synthetic 256^3 x 8 TE volume.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the hot path over one rank's slab: the fit kernel over 256^3 voxels x 8 echoes
-already resident in HBM (t2fit_volume_dev) and, for N > 1, the RCCL all-gather of the four output
-maps that BASELINE.json's north_star asks for.  Weak scaling: every rank fits its own 256^3 slab.
-`value` = voxels fitted by all ranks / wall time (max over ranks) in Mvoxel/s.
+A step = one pass of the hot path over the volume: the fit kernel over voxels x 8 echoes already resident in HBM
+(t2fit_volume_dev) and, for N > 1, the RCCL all-gather of the four output maps that BASELINE.json's north_star asks
+for.  Default: STRONG scaling, as BASELINE.json's metric words it ("256^3 x 8TE ... 1/2/4/8 GPU"): ONE 256^3 volume,
+cut over the N ranks in chunks of 16 Ki voxels dealt rank by rank (fetal_t2mapping_amd/dist.py: every rank gets the
+same share of every region of the mask, contiguous Z-slabs of the ellipsoid do not), each rank fits its share, one
+all-gather puts the four maps of the whole volume on every rank.  `--scaling weak`: every rank fits its own 256^3
+volume (round 1's mode).  `value` = dense voxels of the volume(s) / wall time (max over ranks) in Mvoxel/s.
 
 The JSON line also carries
-  roofline     : achieved algorithmic HBM GB/s of the fit kernel (49 B/voxel at 8 TE: 4*nTE samples
-                 + 1 mask byte + 4 float32 maps) over its mean launch duration, measured
-                 with HIP events on the launch stream inside the library, against 8 TB/s.
-  cpu_baseline : the CPU oracle (oracle/t2fit_oracle.py: the reference's scipy L-BFGS-B loop restated)
-                 timed on this host's cores over a bounded sample of the same masked voxels.
+  roofline     : achieved algorithmic HBM GB/s of the fit kernel (49 B/voxel at 8 TE: 4*nTE samples + 1 mask byte
+                 + 4 float32 maps) over its mean launch duration on rank 0, measured with HIP events
+                 on the launch stream inside the library, against 8 TB/s.
+  cpu_baseline : the CPU oracle (oracle/t2fit_oracle.py: the reference's scipy L-BFGS-B loop restated) timed on this
+                 host's cores over a bounded sample of the same masked voxels; on the same basis as `value` (dense
+                 voxels/s at the bench volume's mask fill), with the fitted-voxel rates of both beside it.
 """
 import argparse
 import ctypes as C
@@ -78,7 +82,11 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--shape", type=int, nargs=3, default=[256, 256, 256], help="per-rank slab Z Y X")
+    p.add_argument("--shape", type=int, nargs=3, default=[256, 256, 256], help="volume Z Y X (per rank with --scaling weak)")
+    p.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                   help="strong (default): one volume cut over the ranks; weak: one volume per rank")
+    p.add_argument("--partition", default="cyclic", choices=["cyclic", "slab"],
+                   help="strong scaling: chunks dealt rank by rank (balanced, default) or contiguous flat ranges")
     p.add_argument("--n-te", type=int, default=8)
     p.add_argument("--fit", default="gaussian_rician", choices=["gaussian", "gaussian_rician", "rician"])
     p.add_argument("--solver", default="lbfgsb", choices=["lbfgsb", "lm", "loglin"])
@@ -87,8 +95,9 @@ def parse():
     p.add_argument("--no-gather", action="store_true", help="skip the all-gather of the maps (N > 1)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration (0 = skip)")
     p.add_argument("--no-also", action="store_true", help="skip the secondary (converged LM float32) measurement")
-    p.add_argument("--reserve-cus", type=int, default=16,
-                   help="N > 1 with the all-gather: CUs the persistent fit kernel leaves free for RCCL's kernels")
+    p.add_argument("--reserve-cus", type=int, default=0,
+                   help="N > 1 with the all-gather: CUs the persistent fit kernel leaves free for RCCL's kernels (A/B "
+                        "switch; off by default: no RCCL run has shown that it pays)")
     return p.parse_args()
 
 
@@ -111,11 +120,15 @@ def cpu_baseline(echoes_rows, te, fit, prior, seconds):
     n = int(min(echoes_rows.shape[0], max(cores * 50, seconds * cores / per_voxel)))
     log(f"cpu baseline: {per_voxel * 1e3:.2f} ms/voxel single process, timing {n} voxels")
     rows = echoes_rows[:n]
-    with mp.get_context("fork").Pool(cores) as pool:
+    pool = mp.get_context("fork").Pool(cores)
+    try:
         t0 = time.perf_counter()
         O.fit_volume(rows, np.arange(n), te, fit, table, prior=prior, pool=pool)
         dt = time.perf_counter() - t0
-    return {"value": n / dt / 1e6, "unit": "Mvoxel/s", "cores": cores, "kind": "port",
+    finally:
+        pool.close()  # workers leave on their own (no SIGTERM: under a profiler that reads as an abort)
+        pool.join()
+    return {"fitted_value": n / dt / 1e6, "unit": "Mvoxel/s", "cores": cores, "kind": "port",
             "sample": f"{n} masked voxels of a 6-slice slab of the same synthetic distribution, scipy {__import__('scipy').__version__} "
                       f"L-BFGS-B loop (oracle/t2fit_oracle.py) on a {cores}-process pool, {dt:.1f} s"}
 
@@ -128,6 +141,7 @@ def main():
 
     import fetal_t2mapping_amd as t2
     from fetal_t2mapping_amd import _abi, synth
+    from fetal_t2mapping_amd import dist as t2dist
     from fetal_t2mapping_amd._lib import check, require_gpu
 
     rank = int(os.environ.get("RANK", "0"))
@@ -161,24 +175,51 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     z, y, x = a.shape
-    n_vox = z * y * x
-    echoes, mask, te = synth.brain_volume_torch((z, y, x), a.n_te, synth.SEED_BASE + 3 + rank, dev)
-    log(f"synthetic slab on device: {n_vox} voxels x {a.n_te} TE")
+    n_vol = z * y * x
+    strong = a.scaling == "strong"
+    # strong: every rank generates the SAME volume (same seed) and keeps its share; weak: one volume per rank
+    echoes, mask, te = synth.brain_volume_torch((z, y, x), a.n_te, synth.SEED_BASE + 3 + (0 if strong else rank), dev)
+    masked_vol = int(mask.sum().item())
+    src_index = None
+    if strong and world > 1:
+        if a.partition == "cyclic":
+            n_mine = t2dist.cyclic_len(n_vol, world)
+            idx = t2dist.cyclic_index(n_vol, rank, world)
+        else:
+            n_mine = t2dist.slab_len(n_vol, world)
+            lo, hi = t2dist.slab_range(n_vol, rank, world)
+            idx = np.full(n_mine, -1, np.int64)
+            idx[: hi - lo] = np.arange(lo, hi)
+        it = torch.from_numpy(np.where(idx >= 0, idx, 0)).to(dev)
+        real = torch.from_numpy(idx >= 0).to(dev)
+        echoes = echoes[:, it].contiguous()                       # this rank's share, resident before the timed region
+        mask = (mask[it] * real.to(torch.uint8)).contiguous()     # padding slots: mask 0
+        del it, real
+        if a.partition == "cyclic":   # rows of the gathered [world * slots] chunk table in voxel order (dist.gather_maps_cyclic)
+            slots = n_mine // t2dist.CHUNK
+            c = np.arange(slots * world, dtype=np.int64)
+            g = c // world
+            src_index = torch.from_numpy(((c % world + t2dist._rotation(g, world)) % world) * slots + g).to(dev)
+    else:
+        n_mine = n_vol
+    n_vox = n_mine
+    masked_mine = int(mask.sum().item())
+    log(f"rank {rank}: {n_vox} voxels x {a.n_te} TE on device ({masked_mine} in the mask), scaling {a.scaling}")
     table = t2.fit_table(a.fit, True)
     cfg = t2.make_config(a.fit, table, te, prior=not a.no_prior, norm=False, solver=a.solver, precision=a.precision)
-    # packed output slab [4, n_vox]: t2, k, sigma, res -- one all-gather moves all four maps.
-    # Two slabs / two gather targets alternate so that the RCCL all-gather of step i (RCCL's own
-    # stream, xGMI) overlaps the fit kernel of step i+1; a slab is reused only after the gather that
+    # packed output [4, n_vox]: t2, k, sigma, res -- one all-gather moves all four maps.
+    # Two packed buffers / two gather targets alternate so that the RCCL all-gather of step i (RCCL's own
+    # stream, xGMI) overlaps the fit kernel of step i+1; a buffer is reused only after the gather that
     # read it has been waited for on the compute stream.
     do_gather = world > 1 and not a.no_gather
     packed = [torch.empty((4, n_vox), dtype=torch.float32, device=dev) for _ in range(2 if do_gather else 1)]
     gathered = [torch.empty((world, 4, n_vox), dtype=torch.float32, device=dev) for _ in range(2)] if do_gather else None
+    ordered = torch.empty((4, world * n_vox), dtype=torch.float32, device=dev) if (do_gather and src_index is not None) else None
     reserved = 0
     if do_gather and a.solver == "lbfgsb" and a.reserve_cus > 0 and "T2FIT_PERSISTENT_BLOCKS" not in os.environ:
         # The reference-trajectory kernel is persistent with one workgroup per CU (its LDS-resident history fills the
-        # CU): launched over every CU it leaves RCCL's all-gather kernel nowhere to run until it drains, and the
-        # gather of step i could not overlap the fit of step i+1.  T2FIT_RESERVE_CUS makes the library launch that
-        # kernel over (CUs - reserve) workgroups.  The library reads the variable once, at its first launch.
+        # CU).  T2FIT_RESERVE_CUS makes the library launch it over (CUs - reserve) workgroups so that RCCL's kernels
+        # find free CUs while it runs.  The library reads the variable once, at its first launch.
         reserved = a.reserve_cus
         os.environ["T2FIT_RESERVE_CUS"] = str(reserved)
     maps_b = []
@@ -194,11 +235,19 @@ def main():
     kernel_ms = []
     step_no = [0]
 
+    def reorder(b):
+        """strong scaling, cyclic partition: the gathered chunk table back into voxel order (one gather of 64 KiB rows)."""
+        if ordered is not None:
+            slots = n_vox // t2dist.CHUNK
+            by_chunk = gathered[b].view(world, 4, slots, t2dist.CHUNK).permute(1, 0, 2, 3).reshape(4, world * slots, t2dist.CHUNK)
+            torch.index_select(by_chunk, 1, src_index, out=ordered.view(4, world * slots, t2dist.CHUNK))
+
     def step(record):
         b = step_no[0] % len(packed)
         step_no[0] += 1
         if pending[b] is not None:
-            pending[b].wait()  # stream-side wait: slab b is free again
+            pending[b].wait()  # stream-side wait: buffer b is free again
+            reorder(b)
             pending[b] = None
         check(lib.t2fit_volume_dev(C.byref(cfg), echoes.data_ptr(), _abi.LAYOUT_TE_MAJOR, mask.data_ptr(), n_vox,
                                    C.byref(maps_b[b]), st))
@@ -207,6 +256,7 @@ def main():
                 parts = [torch.empty((4, n_vox), dtype=torch.float32) for _ in range(world)]
                 dist.all_gather(parts, packed[b].cpu())
                 gathered[b].copy_(torch.stack(parts))
+                reorder(b)
             else:
                 pending[b] = dist.all_gather_into_tensor(gathered[b].view(-1), packed[b].view(-1), async_op=True)
         if record:
@@ -216,6 +266,7 @@ def main():
         for b in range(2):
             if pending[b] is not None:
                 pending[b].wait()
+                reorder(b)
                 pending[b] = None
 
     for _ in range(a.warmup):
@@ -229,7 +280,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step(True)
-    drain()  # every all-gather of the timed steps has completed inside the timed region
+    drain()  # every all-gather (and reordering) of the timed steps has completed inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -240,8 +291,27 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # secondary measurement, same data: the converged bounded-LM solver in float32 (north_star's
-    # "per-lane Levenberg-Marquardt"); reported beside the headline, never as `value`
+    # strong scaling self-check (outside the timed region): the maps every rank now holds for the whole volume are,
+    # bit for bit, the maps of a single-GPU fit of that volume (rank 0 fits it alone and compares)
+    verified = None
+    if strong and do_gather and rank == 0:
+        e_all, m_all, _ = synth.brain_volume_torch((z, y, x), a.n_te, synth.SEED_BASE + 3, dev)
+        alone = torch.empty((4, n_vol), dtype=torch.float32, device=dev)
+        ma = _abi.T2FitMaps()
+        ma.t2, ma.k, ma.sigma, ma.res = (alone[j].data_ptr() for j in range(4))
+        check(lib.t2fit_volume_dev(C.byref(cfg), e_all.data_ptr(), _abi.LAYOUT_TE_MAJOR, m_all.data_ptr(), n_vol, C.byref(ma), st))
+        torch.cuda.synchronize()
+        last = (step_no[0] - 1) % len(packed)
+        if ordered is not None:
+            reorder(last)
+            whole = ordered[:, :n_vol]
+        else:
+            whole = gathered[last].permute(1, 0, 2).reshape(4, world * n_vox)[:, :n_vol]
+        verified = bool(((whole == alone) | (whole.isnan() & alone.isnan())).all().item())
+        del e_all, m_all, alone
+
+    # secondary measurements, same data on this rank: the converged bounded-LM solver (north_star's "per-lane
+    # Levenberg-Marquardt") in float32 and in the reference's float64, and the closed form; never `value`
     def measure(cfg_x):
         """Mean kernel time (HIP events on the launch stream) and mean wall time per launch of one more solver."""
         n2 = max(3, min(10, a.steps))
@@ -260,16 +330,18 @@ def main():
         torch.cuda.synchronize()
         dt2 = (time.perf_counter() - t1) / n2
         kk = float(np.mean(ks))
-        return {"per_gpu_value": round(n_vox / dt2 / 1e6, 3), "unit": "Mvoxel/s", "ms_per_step": round(dt2 * 1e3, 4),
-                "kernel_ms": round(kk, 4),
+        return {"per_gpu_value": round(n_vox / dt2 / 1e6, 3), "per_gpu_fitted_value": round(masked_mine / dt2 / 1e6, 3),
+                "unit": "Mvoxel/s", "ms_per_step": round(dt2 * 1e3, 4), "kernel_ms": round(kk, 4),
                 "roofline_frac": round((4 * a.n_te + 17) * n_vox / (kk * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
 
-    also = also_loglin = None
+    also = also_f64 = also_loglin = None
     if a.solver == "lbfgsb" and a.fit != "rician" and not a.no_also:
+        note = ("converged bounded LM of the same objective; differs from the reference's early-stopped result by design "
+                "(DESIGN.md section 2), no all-gather in this figure")
         cfg2 = t2.make_config(a.fit, table, te, prior=not a.no_prior, norm=False, solver="lm", precision="f32")
-        also = {"solver": "lm", "dtype": "f32", **measure(cfg2),
-                "note": "converged bounded LM of the same objective; differs from the reference's early-stopped "
-                        "result by design (DESIGN.md section 2), no all-gather in this figure"}
+        also = {"solver": "lm", "dtype": "f32", **measure(cfg2), "note": note}
+        cfg2d = t2.make_config(a.fit, table, te, prior=not a.no_prior, norm=False, solver="lm", precision="f64")
+        also_f64 = {"solver": "lm", "dtype": "f64", **measure(cfg2d), "note": note + "; the reference's precision"}
         # the one fit on the path that IS bound by HBM: closed-form log-linear 2-parameter fit of the same stack
         # (BASELINE.json config 2 names it; the reference has no such routine), fit + residual map in one pass
         cfg3 = t2.make_config("gaussian", t2.fit_table("gaussian", True), te, prior=not a.no_prior, norm=False,
@@ -280,49 +352,62 @@ def main():
                                "an extension, not the reference's solver: never `value`"}
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
-        value = world * n_vox / (elapsed / a.steps) / 1e6
+        total_vox = n_vol if strong else world * n_vol
+        total_masked = masked_vol if strong else world * masked_vol  # (weak: every rank's mask has the same size)
+        value = total_vox / (elapsed / a.steps) / 1e6
+        fitted_value = total_masked / (elapsed / a.steps) / 1e6
+        fill = masked_vol / n_vol
         bytes_per_voxel = 4 * a.n_te + 1 + 16
         k_ms = float(np.mean(kernel_ms))
         achieved = bytes_per_voxel * n_vox / (k_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
-        if os.path.exists(tpath):  # HBM bytes per launch from separate rocprofv3 --pmc passes (see profiles/README.md)
+        key = f"{a.fit}/{a.solver}/{a.precision}/{z}x{y}x{x}x{a.n_te}"
+        if os.path.exists(tpath) and n_vox == n_vol:  # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md)
             with open(tpath) as f:
-                t = json.load(f)
-            key = f"{a.fit}/{a.solver}/{a.precision}/{z}x{y}x{x}x{a.n_te}"
-            traffic = t.get(key)
-        masked = int(mask.sum().item())
+                traffic = json.load(f).get(key)
+        part = "one volume" if world == 1 else (f"one volume in {a.partition} shares x{world}" if strong else f"one volume per rank x{world}")
         out = {
             "metric": "Mvoxel/s T2 fit, 256\u00b3\u00d78TE 3-param LM, 1/2/4/8 GPU; % HBM roofline",  # BASELINE.json's metric, verbatim
             "value": round(value, 3), "unit": "Mvoxel/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": "f64" if a.solver == "lbfgsb" else a.precision, "data": "synthetic",
-            "config": {"workload": f"{z}x{y}x{x} voxels x {a.n_te} TE per GPU, {a.fit} objective, "
+            "basis": f"`value` counts every voxel of the volume (SURVEY.md 8d: dense voxels/s); mask fill {fill:.3f}: "
+                     f"`fitted_value` counts the voxels inside the mask, the only ones that are fitted",
+            "fitted_value": round(fitted_value, 3),
+            "gathered_maps_equal_single_gpu_fit": verified,
+            "config": {"workload": f"{z}x{y}x{x} voxels x {a.n_te} TE ({part}), {a.fit} objective, "
                                    f"{ {'lbfgsb': 'reference-trajectory L-BFGS-B', 'lm': 'bounded LM', 'loglin': 'closed-form log-linear'}[a.solver]} solver, "
-                                   f"{'prior' if not a.no_prior else 'no-prior'} bounds, mask fill {masked / n_vox:.2f}",
-                       "solver": a.solver, "fit": a.fit, "n_te": a.n_te, "voxels_per_gpu": n_vox,
-                       "masked_voxels_per_gpu": masked,
-                       "parallelism": f"voxel slabs x{world}" + (" + all-gather of 4 maps (overlapped with the next fit)" if do_gather else ""),
+                                   f"{'prior' if not a.no_prior else 'no-prior'} bounds, mask fill {fill:.2f}",
+                       "solver": a.solver, "fit": a.fit, "n_te": a.n_te, "voxels_total": total_vox,
+                       "masked_voxels_total": total_masked, "voxels_rank0": n_vox, "masked_voxels_rank0": masked_mine,
+                       "parallelism": part + (" + all-gather of 4 maps (overlapped with the next fit)" if do_gather else ""),
                        "cus_left_free_for_rccl": reserved,
                        "metric_note": "BASELINE.json words the metric '3-param LM'; the reference's solver is scipy L-BFGS-B "
                                       "(SURVEY.md F1) and `value` is the solver that reproduces the reference's maps; the "
-                                      "converged LM kernel north_star describes is measured in the same run under `also`"},
+                                      "converged LM kernel north_star describes is measured in the same run under `also` "
+                                      "(float32) and `also_lm_f64` (the reference's precision)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel": "loglin_volume_kernel" if a.solver == "loglin" else "fit_persistent_kernel",
                          "kernel_ms": round(k_ms, 4),
-                         "bytes_per_voxel": bytes_per_voxel,
+                         "bytes_per_voxel": bytes_per_voxel, "voxels_per_launch": n_vox,
                          "note": ("one streaming pass, HBM bound" if a.solver == "loglin" else
-                                  "the fit is float64 VALU bound (exp/sqrt/div per objective evaluation), not HBM "
-                                  "bound: see DESIGN.md section 6")},
+                                  "the fit is float64 VALU-issue bound (about 4500 wave instructions per evaluation round "
+                                  "at one wave per SIMD), not HBM bound: see DESIGN.md section 6 and `alu`")},
         }
-        alu = alu_view(f"{a.fit}/{a.solver}/{a.precision}/{z}x{y}x{x}x{a.n_te}", k_ms)
+        alu = alu_view(key, k_ms) if n_vox == n_vol else None
         if alu is not None:
             out["alu"] = alu
         if cpu is not None:
+            cpu["value"] = cpu["fitted_value"] / fill
+            cpu["basis"] = (f"`value` = dense-volume equivalent: the fitted-voxel rate divided by the bench volume's mask fill "
+                            f"{fill:.3f} (same basis as the headline `value`); `fitted_value` = masked voxels/s as timed")
             out["cpu_baseline"] = cpu
         if also is not None:
             out["also"] = also
+        if also_f64 is not None:
+            out["also_lm_f64"] = also_f64
         if also_loglin is not None:
             out["also_loglin"] = also_loglin
         print(json.dumps(out), flush=True)

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_TE = 32
 
 OK, E_INVALID, E_HIP, E_BOUNDS = 0, -1, -2, -3
@@ -48,6 +48,9 @@ SYMBOLS = [
     ("t2fit_config_default", C.c_int, [C.POINTER(T2FitConfig), C.c_int, C.c_int]),
     ("t2fit_device_count", C.c_int, []),
     ("t2fit_volume_dev", C.c_int, [C.POINTER(T2FitConfig), _P, C.c_int, _P, C.c_int64, C.POINTER(T2FitMaps), _P]),
+    ("t2fit_create", C.c_int, [C.c_int, C.POINTER(_P)]),
+    ("t2fit_destroy", C.c_int, [_P]),
+    ("t2fit_context_volume_host", C.c_int, [_P, C.POINTER(T2FitConfig), _P, C.c_int, _P, C.c_int64, C.POINTER(T2FitMaps)]),
     ("t2fit_volume_host", C.c_int, [C.POINTER(T2FitConfig), _P, C.c_int, _P, C.c_int64, C.POINTER(T2FitMaps), C.c_int]),
     ("t2fit_voxels_host", C.c_int, [C.POINTER(T2FitConfig), _P, C.c_int, C.c_int64, _P, C.c_int64, _P, _P, _P, _P, C.c_int]),
     ("t2fit_voxels_trace_host", C.c_int, [C.POINTER(T2FitConfig), _P, C.c_int, C.c_int64, _P, C.c_int64, _P, _P, _P, _P,

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "t2fit_config.h"
+#include "t2fit_context.h"
 #include "t2fit_dispatch.h"
 
 using namespace t2fit;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void loglin_volume_kernel(const LaneParams 
 // (divergent, cheap); the wave leaves when a __ballot shows no lane has work and the queue is dry.
 constexpr int kChunkLarge = 256;  // voxels a wave takes from the global queue at a time
 constexpr int kChunkSmall = 64;   // small volumes (phantoms): more, smaller chunks so that every wave gets work
-constexpr int64_t kSmallVolume = 1 << 21;
+constexpr int64_t kSmallVolume = 1 << 20;
 constexpr int kQueueCap = 64 + kChunkLarge;
 constexpr int kDiagBlocks = 11, kDiagWords = 3 * kDiagBlocks;  // -DT2_PHASE_STAMPS: (cycles, lanes, entries) per block
 constexpr int kCounterWords = 16 + kDiagWords;                  // chunk counter + diagnostic totals
@@ -927,40 +928,7 @@ int t2fit_volume_dev(const t2fit_config* cfg, const float* echoes_dev, int layou
   return launch_fit(cfg, echoes_dev, layout, mask_dev, n_vox, dm, (hipStream_t)stream);
 }
 
-int t2fit_volume_host(const t2fit_config* cfg, const float* echoes, int layout, const uint8_t* mask, int64_t n_vox,
-                      const t2fit_maps* maps, int device) {
-  int rc = check_common(cfg, echoes, layout, n_vox);
-  if (rc != T2FIT_OK) return rc;
-  if (!maps || !maps->t2 || !maps->k || !maps->sigma || !maps->res)
-    return fail(T2FIT_E_INVALID, "maps->t2/k/sigma/res must be non-NULL");
-  if (n_vox == 0) return T2FIT_OK;
-  T2_HIP(hipSetDevice(device));
-  const int n_te = cfg->n_te;
-  // Large volumes of the slow (reference-trajectory) solver go through in a few slabs of voxels (voxels are
-  // independent, a slab's result does not depend on the split): the host->device copy of slab s+1 and the
-  // device->host copy of slab s-1 run beside the fit of slab s, each direction on its own stream.  Measured on
-  // 256^3 x 8 TE from pageable numpy buffers: 69 ms in one piece, 55 ms in four slabs; more slabs, or slabs for
-  // the fast solvers (whose time is all copies), lose to the per-copy overhead of pageable transfers.  Slab
-  // lengths are multiples of 4096 voxels so that every slab keeps the alignment the vectorised kernels want.
-  const int64_t kSlabMin = 4 << 20;
-  int n_slabs = cfg->solver == T2FIT_SOLVER_LBFGSB ? (int)std::min<int64_t>(4, std::max<int64_t>(1, n_vox / kSlabMin)) : 1;
-  if (const char* e = std::getenv("T2FIT_HOST_SLABS")) n_slabs = std::max(1, std::min(64, std::atoi(e)));
-  const int64_t slab = (((n_vox + n_slabs - 1) / n_slabs) + 4095) & ~(int64_t)4095;
-  n_slabs = (int)((n_vox + slab - 1) / slab);
-  hipStream_t s_in = nullptr, s_fit = nullptr, s_out = nullptr;
-  std::vector<hipEvent_t> ev_in(n_slabs, nullptr), ev_fit(n_slabs, nullptr);
-  char* buf = nullptr;
-  auto cleanup = [&]() {
-    if (s_in) (void)hipStreamSynchronize(s_in);
-    if (s_fit) (void)hipStreamSynchronize(s_fit);
-    if (s_out) (void)hipStreamSynchronize(s_out);
-    for (auto& ev : ev_in) if (ev) (void)hipEventDestroy(ev);
-    for (auto& ev : ev_fit) if (ev) (void)hipEventDestroy(ev);
-    if (buf) (void)hipFree(buf);
-    if (s_in) (void)hipStreamDestroy(s_in);
-    if (s_fit) (void)hipStreamDestroy(s_fit);
-    if (s_out) (void)hipStreamDestroy(s_out);
-  };
+// ---- host seam through a context (t2fit_context.h) -------------------------------------------------------------
 #define T2_HIP_C(call)                                                          \
   do {                                                                          \
     hipError_t e_ = (call);                                                     \
@@ -969,11 +937,107 @@ int t2fit_volume_host(const t2fit_config* cfg, const float* echoes, int layout, 
       return fail(T2FIT_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     }                                                                           \
   } while (0)
-  T2_HIP_C(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
-  T2_HIP_C(hipStreamCreateWithFlags(&s_fit, hipStreamNonBlocking));
-  T2_HIP_C(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+
+int t2fit_create(int device, t2fit_context** out) {
+  if (!out) return fail(T2FIT_E_INVALID, "t2fit_create: out is NULL");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
+    (void)hipGetLastError();
+    return fail(T2FIT_E_HIP, "t2fit_create: no such HIP device");
+  }
+  T2_HIP(hipSetDevice(device));
+  t2fit_context* c = new t2fit_context;
+  c->device = device;
+  auto cleanup = [&]() {
+    if (c->s_in) (void)hipStreamDestroy(c->s_in);
+    if (c->s_fit) (void)hipStreamDestroy(c->s_fit);
+    if (c->s_out) (void)hipStreamDestroy(c->s_out);
+    delete c;
+  };
+  T2_HIP_C(hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+  T2_HIP_C(hipStreamCreateWithFlags(&c->s_fit, hipStreamNonBlocking));
+  T2_HIP_C(hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+  int threads = 8;
+  if (const char* e = std::getenv("T2FIT_COPY_THREADS")) threads = std::max(0, std::min(64, std::atoi(e)));
+  c->pool = new t2fit::CopyPool(threads);
+  *out = c;
+  return T2FIT_OK;
+}
+
+int t2fit_destroy(t2fit_context* c) {
+  if (!c) return T2FIT_OK;
+  {
+    std::lock_guard<std::mutex> g(c->busy);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->s_in);
+    (void)hipStreamSynchronize(c->s_fit);
+    (void)hipStreamSynchronize(c->s_out);
+    for (auto ev : c->events) (void)hipEventDestroy(ev);
+    for (int j = 0; j < 2; ++j) {
+      if (c->pin_in[j]) (void)hipHostFree(c->pin_in[j]);
+      if (c->pin_out[j]) (void)hipHostFree(c->pin_out[j]);
+    }
+    if (c->dev) (void)hipFree(c->dev);
+    (void)hipStreamDestroy(c->s_in);
+    (void)hipStreamDestroy(c->s_fit);
+    (void)hipStreamDestroy(c->s_out);
+    delete c->pool;
+  }
+  delete c;
+  return T2FIT_OK;
+}
+
+int t2fit_context_volume_host(t2fit_context* c, const t2fit_config* cfg, const float* echoes, int layout,
+                              const uint8_t* mask, int64_t n_vox, const t2fit_maps* maps) {
+  if (!c) return fail(T2FIT_E_INVALID, "context is NULL");
+  int rc = check_common(cfg, echoes, layout, n_vox);
+  if (rc != T2FIT_OK) return rc;
+  if (!maps || !maps->t2 || !maps->k || !maps->sigma || !maps->res)
+    return fail(T2FIT_E_INVALID, "maps->t2/k/sigma/res must be non-NULL");
+  if (n_vox == 0) return T2FIT_OK;
+  std::lock_guard<std::mutex> guard(c->busy);
+  T2_HIP(hipSetDevice(c->device));
+  const int n_te = cfg->n_te;
+  // Slabs of about 2.2 M voxels (multiples of 4096, so that every slab keeps the alignment the vectorised kernels
+  // want and stays on the large-volume kernels): short enough that filling and draining the pipeline costs little,
+  // long enough that a slab's fit covers the host-side copies of its neighbours.
+  int64_t slab = (int64_t)9 << 18;  // 2,359,296
+  if (const char* e = std::getenv("T2FIT_HOST_SLABS")) {  // A/B switch and tests: number of slabs
+    const int64_t want = std::max(1, std::min(4096, std::atoi(e)));
+    slab = (n_vox + want - 1) / want;
+  }
+  slab = std::max<int64_t>(4096, (slab + 4095) & ~(int64_t)4095);
+  const int n_slabs = (int)((n_vox + slab - 1) / slab);
+  // outputs: float maps (t2, k, sigma, res, r2, fun, t2_se), then nit (int32), then status (uint8)
+  float* host_f[7] = {maps->t2, maps->k, maps->sigma, maps->res, maps->r2, maps->fun, maps->t2_se};
+  const size_t slab_in = (size_t)slab * n_te * 4 + (size_t)slab;          // samples + mask bytes of one slab
+  const size_t slab_out = (size_t)slab * (7 * 4 + 4 + 1);                  // every optional map wanted
+  auto cleanup = [&]() {
+    (void)hipStreamSynchronize(c->s_in);
+    (void)hipStreamSynchronize(c->s_fit);
+    (void)hipStreamSynchronize(c->s_out);
+  };
+  if (c->pin_in_cap < slab_in) {
+    for (int j = 0; j < 2; ++j) {
+      if (c->pin_in[j]) (void)hipHostFree(c->pin_in[j]);
+      c->pin_in[j] = nullptr;
+    }
+    c->pin_in_cap = 0;
+    for (int j = 0; j < 2; ++j) T2_HIP_C(hipHostMalloc((void**)&c->pin_in[j], slab_in, hipHostMallocDefault));
+    c->pin_in_cap = slab_in;
+  }
+  if (c->pin_out_cap < slab_out) {
+    for (int j = 0; j < 2; ++j) {
+      if (c->pin_out[j]) (void)hipHostFree(c->pin_out[j]);
+      c->pin_out[j] = nullptr;
+    }
+    c->pin_out_cap = 0;
+    for (int j = 0; j < 2; ++j) T2_HIP_C(hipHostMalloc((void**)&c->pin_out[j], slab_out, hipHostMallocDefault));
+    c->pin_out_cap = slab_out;
+  }
+  // device arena: echoes (slab after slab, each (n_te, len) or (len, n_te)) | 7 float maps | nit | mask | status
   const size_t nb_e = (size_t)n_vox * n_te * sizeof(float);
-  // one allocation: echoes (slab after slab, each (n_te, len) or (len, n_te)) | 7 float maps | nit | mask | status
   const size_t off_maps = (nb_e + 255) & ~(size_t)255;
   const size_t map_b = (((size_t)n_vox * 4) + 255) & ~(size_t)255;
   const size_t off_nit = off_maps + 7 * map_b;
@@ -981,52 +1045,114 @@ int t2fit_volume_host(const t2fit_config* cfg, const float* echoes, int layout, 
   const size_t byte_b = ((size_t)n_vox + 255) & ~(size_t)255;
   const size_t off_status = off_mask + byte_b;
   const size_t total = off_status + byte_b;
-  T2_HIP_C(hipMalloc((void**)&buf, total));
+  if (c->dev_cap < total) {
+    if (c->dev) (void)hipFree(c->dev);
+    c->dev = nullptr;
+    c->dev_cap = 0;
+    T2_HIP_C(hipMalloc((void**)&c->dev, total));
+    c->dev_cap = total;
+  }
+  char* buf = c->dev;
+  while (c->events.size() < (size_t)3 * n_slabs) {
+    hipEvent_t ev;
+    T2_HIP_C(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    c->events.push_back(ev);
+  }
+  hipEvent_t* ev_in = c->events.data();
+  hipEvent_t* ev_fit = ev_in + n_slabs;
+  hipEvent_t* ev_out = ev_fit + n_slabs;
   float* fm[7];
   for (int j = 0; j < 7; ++j) fm[j] = (float*)(buf + off_maps + j * map_b);
-  float* host_f[7] = {maps->t2, maps->k, maps->sigma, maps->res, maps->r2, maps->fun, maps->t2_se};
   const bool want[7] = {true, true, true, true, maps->r2 != nullptr, maps->fun != nullptr, maps->t2_se != nullptr};
-  auto copy_out = [&](int k) -> hipError_t {  // maps of slab k, after its fit
-    const int64_t lo = (int64_t)k * slab, len = std::min<int64_t>(slab, n_vox - lo);
-    hipError_t e = hipStreamWaitEvent(s_out, ev_fit[k], 0);
+  auto span = [&](int k, int64_t& lo, int64_t& len) { lo = (int64_t)k * slab; len = std::min<int64_t>(slab, n_vox - lo); };
+  // device -> pinned: the maps of slab k, packed one after the other in its staging slot
+  auto queue_d2h = [&](int k) -> hipError_t {
+    int64_t lo, len;
+    span(k, lo, len);
+    char* dst = c->pin_out[k & 1];
+    hipError_t e = hipStreamWaitEvent(c->s_out, ev_fit[k], 0);
+    size_t off = 0;
     for (int j = 0; j < 7 && e == hipSuccess; ++j)
-      if (want[j]) e = hipMemcpyAsync(host_f[j] + lo, fm[j] + lo, (size_t)len * 4, hipMemcpyDeviceToHost, s_out);
-    if (e == hipSuccess && maps->nit)
-      e = hipMemcpyAsync(maps->nit + lo, buf + off_nit + (size_t)lo * 4, (size_t)len * 4, hipMemcpyDeviceToHost, s_out);
-    if (e == hipSuccess && maps->status)
-      e = hipMemcpyAsync(maps->status + lo, buf + off_status + lo, (size_t)len, hipMemcpyDeviceToHost, s_out);
+      if (want[j]) { e = hipMemcpyAsync(dst + off, fm[j] + lo, (size_t)len * 4, hipMemcpyDeviceToHost, c->s_out); off += (size_t)len * 4; }
+    if (e == hipSuccess && maps->nit) { e = hipMemcpyAsync(dst + off, buf + off_nit + (size_t)lo * 4, (size_t)len * 4, hipMemcpyDeviceToHost, c->s_out); off += (size_t)len * 4; }
+    if (e == hipSuccess && maps->status) e = hipMemcpyAsync(dst + off, buf + off_status + lo, (size_t)len, hipMemcpyDeviceToHost, c->s_out);
+    if (e == hipSuccess) e = hipEventRecord(ev_out[k], c->s_out);
     return e;
   };
+  // pinned -> the caller's arrays (worker threads)
+  auto finish_out = [&](int k) -> hipError_t {
+    int64_t lo, len;
+    span(k, lo, len);
+    hipError_t e = hipEventSynchronize(ev_out[k]);
+    if (e != hipSuccess) return e;
+    const char* src = c->pin_out[k & 1];
+    std::vector<t2fit::CopyPool::Row> rows;
+    size_t off = 0;
+    for (int j = 0; j < 7; ++j)
+      if (want[j]) { rows.push_back({host_f[j] + lo, src + off, (size_t)len * 4}); off += (size_t)len * 4; }
+    if (maps->nit) { rows.push_back({maps->nit + lo, src + off, (size_t)len * 4}); off += (size_t)len * 4; }
+    if (maps->status) rows.push_back({maps->status + lo, src + off, (size_t)len});
+    c->pool->copy(rows);
+    return hipSuccess;
+  };
   for (int k = 0; k < n_slabs; ++k) {
-    const int64_t lo = (int64_t)k * slab, len = std::min<int64_t>(slab, n_vox - lo);
+    int64_t lo, len;
+    span(k, lo, len);
+    char* stage = c->pin_in[k & 1];
+    if (k >= 2) T2_HIP_C(hipEventSynchronize(ev_in[k - 2]));  // the DMA out of this slot has finished
+    std::vector<t2fit::CopyPool::Row> rows;
+    if (layout == T2FIT_LAYOUT_TE_MAJOR) {  // n_te rows of `len` samples out of planes of n_vox
+      for (int i = 0; i < n_te; ++i) rows.push_back({stage + (size_t)i * len * 4, echoes + (size_t)i * n_vox + lo, (size_t)len * 4});
+    } else {
+      rows.push_back({stage, echoes + (size_t)lo * n_te, (size_t)len * n_te * 4});
+    }
+    if (mask) rows.push_back({stage + (size_t)len * n_te * 4, mask + lo, (size_t)len});
+    c->pool->copy(rows);
     float* d_e = (float*)buf + (size_t)lo * n_te;  // this slab's block of the device stack
-    if (layout == T2FIT_LAYOUT_TE_MAJOR)           // n_te rows of `len` samples out of planes of n_vox
-      T2_HIP_C(hipMemcpy2DAsync(d_e, (size_t)len * 4, echoes + lo, (size_t)n_vox * 4, (size_t)len * 4, (size_t)n_te,
-                                hipMemcpyHostToDevice, s_in));
-    else
-      T2_HIP_C(hipMemcpyAsync(d_e, echoes + (size_t)lo * n_te, (size_t)len * n_te * 4, hipMemcpyHostToDevice, s_in));
+    T2_HIP_C(hipMemcpyAsync(d_e, stage, (size_t)len * n_te * 4, hipMemcpyHostToDevice, c->s_in));
     uint8_t* dmask = nullptr;
     if (mask) {
       dmask = (uint8_t*)(buf + off_mask) + lo;
-      T2_HIP_C(hipMemcpyAsync(dmask, mask + lo, (size_t)len, hipMemcpyHostToDevice, s_in));
+      T2_HIP_C(hipMemcpyAsync(dmask, stage + (size_t)len * n_te * 4, (size_t)len, hipMemcpyHostToDevice, c->s_in));
     }
-    T2_HIP_C(hipEventCreateWithFlags(&ev_in[k], hipEventDisableTiming));
-    T2_HIP_C(hipEventCreateWithFlags(&ev_fit[k], hipEventDisableTiming));
-    T2_HIP_C(hipEventRecord(ev_in[k], s_in));
-    T2_HIP_C(hipStreamWaitEvent(s_fit, ev_in[k], 0));
+    T2_HIP_C(hipEventRecord(ev_in[k], c->s_in));
+    T2_HIP_C(hipStreamWaitEvent(c->s_fit, ev_in[k], 0));
     DevMaps dm{fm[0] + lo, fm[1] + lo, fm[2] + lo, fm[3] + lo, maps->r2 ? fm[4] + lo : nullptr,
                maps->fun ? fm[5] + lo : nullptr, maps->t2_se ? fm[6] + lo : nullptr,
                maps->nit ? (int32_t*)(buf + off_nit) + lo : nullptr,
                maps->status ? (uint8_t*)(buf + off_status) + lo : nullptr, nullptr, nullptr};
-    rc = launch_fit(cfg, d_e, layout, dmask, len, dm, s_fit);
+    rc = launch_fit(cfg, d_e, layout, dmask, len, dm, c->s_fit);
     if (rc != T2FIT_OK) { cleanup(); return rc; }
-    T2_HIP_C(hipEventRecord(ev_fit[k], s_fit));
-    if (k > 0) T2_HIP_C(copy_out(k - 1));  // queued after this slab's host->device copy (one shared copy queue)
+    T2_HIP_C(hipEventRecord(ev_fit[k], c->s_fit));
+    // the device -> host copy of the previous slab is queued behind this slab's host -> device copy: both directions
+    // share one copy queue, and a queued copy that waits for a kernel would hold up every copy behind it
+    if (k >= 1) T2_HIP_C(queue_d2h(k - 1));
+    if (k >= 2) T2_HIP_C(finish_out(k - 2));
   }
-  T2_HIP_C(copy_out(n_slabs - 1));
-  T2_HIP_C(hipStreamSynchronize(s_out));
-  cleanup();
+  T2_HIP_C(queue_d2h(n_slabs - 1));
+  if (n_slabs >= 2) T2_HIP_C(finish_out(n_slabs - 2));
+  T2_HIP_C(finish_out(n_slabs - 1));
   return T2FIT_OK;
+}
+
+// The same seam without a context of the caller's: a per-device default context, created on first use and kept
+// for the life of the process.
+int t2fit_volume_host(const t2fit_config* cfg, const float* echoes, int layout, const uint8_t* mask, int64_t n_vox,
+                      const t2fit_maps* maps, int device) {
+  static std::mutex m;
+  static std::vector<t2fit_context*> ctxs;
+  t2fit_context* c = nullptr;
+  {
+    std::lock_guard<std::mutex> g(m);
+    if (device >= 0 && (size_t)device < ctxs.size()) c = ctxs[device];
+    if (!c) {
+      const int rc = t2fit_create(device, &c);
+      if (rc != T2FIT_OK) return rc;
+      if ((size_t)device >= ctxs.size()) ctxs.resize(device + 1, nullptr);
+      ctxs[device] = c;
+    }
+  }
+  return t2fit_context_volume_host(c, cfg, echoes, layout, mask, n_vox, maps);
 }
 
 static int voxels_host_impl(const t2fit_config* cfg, const float* echoes, int layout, int64_t n_vox, const int64_t* idx,

@@ -255,16 +255,25 @@ def fit_volume(echoes, mask, TEeffs, fit, fit_params, prior=True, norm=False, *,
                                        C.c_void_p(st)))
         return out
     e = np.ascontiguousarray(echoes, dtype=np.float32)
-    m = None if mask is None else np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
-    if m is not None and m.size != n:
-        raise ValueError("mask shape does not match the echoes")
-    f32 = lambda: np.empty(spatial, np.float32)  # noqa: E731
-    out = T2Maps(f32(), f32(), f32(), f32())
-    out.status = np.empty(spatial, np.uint8)
-    if extras:
-        out.r2, out.fun, out.nit, out.t2_se = f32(), f32(), np.empty(spatial, np.int32), f32()
+    m = None
+    if mask is not None:
+        m = np.asarray(mask)
+        # the kernels test mask != 0 themselves: one-byte masks go in as they are
+        m = np.ascontiguousarray(m).view(np.uint8) if m.dtype.itemsize == 1 else np.ascontiguousarray(m != 0, dtype=np.uint8)
+        if m.size != n:
+            raise ValueError("mask shape does not match the echoes")
+    if out is None:  # (callers that fit one volume after the other may hand the previous T2Maps back in as `out`)
+        f32 = lambda: np.empty(spatial, np.float32)  # noqa: E731
+        out = T2Maps(f32(), f32(), f32(), f32())
+        if extras:
+            out.r2, out.fun, out.nit, out.t2_se = f32(), f32(), np.empty(spatial, np.int32), f32()
+    want_status = out.status is not None
+    if out.status is None:
+        out.status = np.empty(spatial, np.uint8)
     for name in ("t2", "k", "sigma", "res", "r2", "fun", "nit", "status", "t2_se"):
         a = getattr(out, name)
+        if a is not None and not (isinstance(a, np.ndarray) and a.flags.c_contiguous and a.size == n):
+            raise ValueError(f"out.{name} must be a C-contiguous numpy array of the spatial shape")
         setattr(maps, name, None if a is None else a.ctypes.data)
     check(lib.t2fit_volume_host(C.byref(cfg), e.ctypes.data, lay, None if m is None else m.ctypes.data, n,
                                 C.byref(maps), int(device)))
@@ -272,7 +281,7 @@ def fit_volume(echoes, mask, TEeffs, fit, fit_params, prior=True, norm=False, *,
         bad = int(np.flatnonzero(out.status.reshape(-1) == _abi.ST_INFEASIBLE)[0])
         raise ValueError("LBFGSB - one of the lower bounds is greater than an upper bound. "
                          f"(voxel {bad}: S(TE0) exceeds the no-prior upper bound)")
-    if not extras:
+    if not extras and not want_status:
         out.status = None
     return out
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define T2FIT_ABI_VERSION 2
+#define T2FIT_ABI_VERSION 3
 #define T2FIT_MAX_TE 32
 
 /* error codes */
@@ -135,10 +135,24 @@ int t2fit_device_count(void);
 int t2fit_volume_dev(const t2fit_config *cfg, const float *echoes_dev, int layout,
                      const uint8_t *mask_dev, int64_t n_vox, const t2fit_maps *maps, void *stream);
 
-/* Same seam with host buffers (numpy arrays): allocates device staging, copies in, fits, copies
- * the requested maps out, synchronises.  `device` = HIP device ordinal.  Large volumes of the L-BFGS-B
- * solver are sent through in a few voxel slabs so that copies run beside fits; the maps do not depend
- * on the split (voxels are independent). */
+/* Context of the host seam: the state a sequence of numpy-in / numpy-out fits shares (run_t2mapping.py:358 fits one
+ * (sub, ses) after the other): three HIP streams, recycled events, a grow-only device arena, two page-locked
+ * staging slots per direction and a few copy threads (T2FIT_COPY_THREADS, default 8).  One call at a time per
+ * context; contexts of different devices (or several per device) are independent. */
+typedef struct t2fit_context t2fit_context;
+int t2fit_create(int device, t2fit_context **out);
+int t2fit_destroy(t2fit_context *ctx); /* waits for outstanding work; NULL is a no-op */
+
+/* Volume seam, host buffers (numpy arrays): replaces run_t2mapping.py:411-461 for one (sub,ses).  The volume goes
+ * through in slabs of about 2 M voxels: while one slab is fitted the worker threads copy the next one's samples from
+ * the caller's (pageable) arrays into page-locked staging and the previous one's maps out of it, so the device only
+ * DMAs from and to page-locked memory.  The maps do not depend on the split (voxels are independent).  Synchronous:
+ * the maps are complete on return. */
+int t2fit_context_volume_host(t2fit_context *ctx, const t2fit_config *cfg, const float *echoes, int layout,
+                              const uint8_t *mask, int64_t n_vox, const t2fit_maps *maps);
+
+/* The same without a context of the caller's: uses a per-device context that the library creates on first use
+ * and keeps for the life of the process.  `device` = HIP device ordinal. */
 int t2fit_volume_host(const t2fit_config *cfg, const float *echoes, int layout, const uint8_t *mask,
                       int64_t n_vox, const t2fit_maps *maps, int device);
 

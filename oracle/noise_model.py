@@ -63,3 +63,18 @@ def perturbed_fit_rows(args):
                          bounds=list(zip(lb, ub)), options=fp["options"], jac=False)
         out.append((r.x, r.nit, r.success))
     return out
+
+
+def reference_fit_rows(args):
+    """Pool worker: the unperturbed reference-equivalent fit (oracle.fit_voxel) of rows ``idx``.
+    ``args = (idx, fit, low_field, prior, te, rows)`` -> list of (x, nit, success)."""
+    from . import t2fit_oracle as O
+
+    idx, fit, low_field, prior, te, rows = args
+    fp = O.fit_table(fit, low_field)
+    out = []
+    for v in idx:
+        with np.errstate(all="ignore"):
+            x, ok, nit, f, _ = O.fit_voxel(int(v), fit, fp, te, rows, prior, False, want_trace=False)
+        out.append((x, nit, ok))
+    return out

@@ -73,18 +73,44 @@ def test_config_tables_and_argument_errors_without_gpu(lib):
     assert b"n_te" in lib.t2fit_last_error()
 
 
-def test_product_has_no_cpu_path(monkeypatch):
-    """Without a HIP device every compute entry point of the host mirror raises."""
+def test_product_has_no_cpu_path():
+    """Without a HIP device every compute entry point of the host mirror raises; the product never imports the
+    test oracle (checked in a fresh interpreter: this test process has the oracle loaded by other tests)."""
+    import subprocess
+
     import numpy as np
 
     import fetal_t2mapping_amd as t2
     from fetal_t2mapping_amd._lib import load
 
-    if load().t2fit_device_count() > 0:
-        pytest.skip("a GPU is visible")
-    with pytest.raises(RuntimeError, match="no HIP device"):
-        t2.fit_volume(np.ones((3, 1, 1, 4), np.float32), None, [114.0, 202.0, 299.0], "gaussian",
-                      t2.fit_table("gaussian", True))
-    src = open(os.path.join(REPO, "fetal_t2mapping_amd", "t2map.py")).read()
-    assert "oracle" not in src.replace("oracle/", "")  # the product never imports the test oracle
-    assert "oracle" not in sys.modules or True
+    if load().t2fit_device_count() == 0:
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            t2.fit_volume(np.ones((3, 1, 1, 4), np.float32), None, [114.0, 202.0, 299.0], "gaussian",
+                          t2.fit_table("gaussian", True))
+    pkg = os.path.join(REPO, "fetal_t2mapping_amd")
+    for name in os.listdir(pkg):
+        if name.endswith(".py"):
+            src = open(os.path.join(pkg, name)).read()
+            assert "import oracle" not in src and "from oracle" not in src, name
+    code = ("import sys; sys.path.insert(0, %r); import fetal_t2mapping_amd, fetal_t2mapping_amd.cli, "
+            "fetal_t2mapping_amd.dist, fetal_t2mapping_amd.stream; "
+            "assert not [m for m in sys.modules if m == 'oracle' or m.startswith('oracle.')], 'oracle imported'" % REPO)
+    subprocess.run([sys.executable, "-c", code], check=True)
+
+
+def test_missing_library_fails_loudly():
+    """No library, no fit: with T2FIT_LIB pointing nowhere the loader raises instead of falling back to anything
+    (runs on the GPU box as well as here: the property matters where the product runs)."""
+    import subprocess
+
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np, fetal_t2mapping_amd as t2\n"
+            "try:\n"
+            "    t2.fit_volume(np.ones((3, 1, 1, 4), np.float32), None, [114.0, 202.0, 299.0], 'gaussian',\n"
+            "                  {'initial_guess': [650, 165], 'param_bounds': [(600, 10000), (10, 600)], 'solver': 'L-BFGS-B', 'options': {}})\n"
+            "except RuntimeError as e:\n"
+            "    assert 'is missing' in str(e) and 'no CPU fallback' in str(e), e\n"
+            "    print('raised')\n" % REPO)
+    env = dict(os.environ, T2FIT_LIB="/nonexistent/libt2fit_hip.so")
+    out = subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True, env=env)
+    assert out.stdout.strip() == "raised"

@@ -35,6 +35,15 @@ def t2():
     return m
 
 
+def test_no_cpu_path_on_the_gpu_box():
+    """The no-CPU-path property asserted where the product runs: a missing library raises (fresh interpreter with
+    T2FIT_LIB pointing nowhere) and the product never imports the oracle."""
+    import test_abi
+
+    test_abi.test_missing_library_fails_loudly()
+    test_abi.test_product_has_no_cpu_path()
+
+
 def _table(t2, d):
     return t2.fit_table(str(d["mode"]), bool(d["low_field"]))
 
@@ -333,6 +342,72 @@ def test_lbfgsb_stable_set(t2, model):
     assert n_nit <= 5e-3 * n_stable, (n_nit, n_stable)
 
 
+# ---------------------------------------------------------------------------------------------
+# parity at scale: 20 000 voxels per configuration against the live oracle on the box's host cores
+# ---------------------------------------------------------------------------------------------
+AT_SCALE_N = 20000
+AT_SCALE_CONFIGS = [("gaussian", True), ("gaussian", False), ("gaussian_rician", True), ("gaussian_rician", False),
+                    ("rician", True)]
+
+
+@pytest.fixture(scope="module")
+def at_scale_reference():
+    """Oracle and one-ulp-perturbed oracle (the yardstick) for AT_SCALE_N masked voxels of the bench distribution,
+    five configurations, computed once on a spawned pool over the host cores (about a minute on 16 cores)."""
+    import multiprocessing as mp
+
+    from fetal_t2mapping_amd import synth
+    from oracle.noise_model import perturbed_fit_rows, reference_fit_rows
+
+    ev, mv, te = synth.brain_volume((8, 128, 128), 8, synth.SEED_BASE + 3)
+    rows = np.ascontiguousarray(ev.reshape(8, -1)[:, mv.reshape(-1) != 0].T)[:AT_SCALE_N]
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    chunks = [c for c in np.array_split(np.arange(len(rows)), cores * 4) if len(c)]
+    ref = {}
+    with mp.get_context("spawn").Pool(cores) as pool:
+        for fit, prior in AT_SCALE_CONFIGS:
+            plain = [r for part in pool.map(reference_fit_rows, [(c, fit, True, prior, te, rows) for c in chunks])
+                     for r in part]
+            pert = [r for part in pool.map(perturbed_fit_rows, [(c, fit, True, prior, te, rows, 7 + i)
+                                                                for i, c in enumerate(chunks)]) for r in part]
+            ref[(fit, prior)] = (np.array([r[0] for r in plain]), np.array([r[2] for r in plain]),
+                                 np.array([r[1] for r in plain]), np.array([r[0] for r in pert]),
+                                 np.array([r[2] for r in pert]))
+    return rows, te, ref
+
+
+@pytest.mark.parametrize("fit,prior", AT_SCALE_CONFIGS, ids=[f"{f}-{'prior' if p else 'noprior'}" for f, p in AT_SCALE_CONFIGS])
+def test_lbfgsb_parity_at_scale(t2, at_scale_reference, fit, prior):
+    """HIP lane solver against the live oracle on 20 000 voxels of the bench distribution (8 TE), measured with the
+    yardstick of what the reference reaches against ITSELF when its exp / log / i0e move by one ulp:
+      * fraction of voxels with T2 within 1 ms: HIP >= yardstick - 0.01
+      * median, 90th and 99th percentile of |dT2|: HIP <= 1.2 x yardstick (+ 1e-3 ms)
+      * `success` equal on >= 99.9 %; iteration count equal at least as often as the yardstick - 0.01."""
+    rows, te, ref = at_scale_reference
+    x_ref, ok_ref, nit_ref, x_pert, ok_pert = ref[(fit, prior)]
+    x, ok, nit, fun, st = t2.fit_voxels(np.arange(len(rows)), fit, t2.fit_table(fit, True), te, rows, prior, False)
+    dt = np.abs(x[:, 1] - x_ref[:, 1])
+    dtp = np.abs(x_pert[:, 1] - x_ref[:, 1])
+    frac, frac_p = float(np.mean(dt <= T2_TOL_MS)), float(np.mean(dtp <= T2_TOL_MS))
+    report = {"config": f"{fit}/{'prior' if prior else 'noprior'}", "n": len(rows), "hip_within_1ms": frac,
+              "reference_vs_itself_within_1ms": frac_p, "success_equal": float(np.mean(ok == ok_ref)),
+              "nit_equal": float(np.mean(nit == nit_ref))}
+    for q in (50, 90, 99):
+        report[f"hip_p{q}_ms"] = float(np.percentile(dt, q))
+        report[f"reference_vs_itself_p{q}_ms"] = float(np.percentile(dtp, q))
+    print("parity_at_scale " + repr(report))
+    out_dir = os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+
+        with open(os.path.join(out_dir, "parity_at_scale_suite.jsonl"), "a") as f:
+            f.write(json.dumps(report) + "\n")
+    assert frac >= frac_p - 0.01, report
+    for q in (50, 90, 99):
+        assert report[f"hip_p{q}_ms"] <= 1.2 * report[f"reference_vs_itself_p{q}_ms"] + 1e-3, report
+    assert report["success_equal"] >= 0.999, report
+
+
 def test_lbfgsb_volume_matches_reference_volume(t2):
     """The whole-volume golden (reference process_t2maps run, gaussian / no prior)."""
     d = np.load(os.path.join(GOLDEN, "volume_lf_gaussian_noprior.npz"))
@@ -347,8 +422,14 @@ def test_lbfgsb_volume_matches_reference_volume(t2):
     dt = np.abs(maps.t2[mask] - d["t2"][mask])
     assert np.mean(dt <= T2_TOL_MS) >= 0.95 and np.median(dt) <= 0.02
     assert np.all(maps.sigma == 0)  # 2-parameter model leaves the sigma map at zero (:455-456)
-    close = dt <= 1e-3
-    assert np.max(np.abs(maps.res[mask][close] - d["res"][mask][close])) <= 0.05
+    # residual map, every masked voxel: res = mean_i(y_i - k exp(-t_i/T2)) is Lipschitz in the parameters,
+    # |d res / d k| <= 1 and |d res / d T2| <= k / (e T2) (t exp(-t/T2) <= T2/e), so the library's map may differ from
+    # the reference's by RES_TOL (float32 map of float64 predictions) plus what its parameter differences explain
+    k_a, k_b = maps.k[mask].astype(np.float64), d["k"][mask].astype(np.float64)
+    t_a, t_b = maps.t2[mask].astype(np.float64), d["t2"][mask].astype(np.float64)
+    bound = RES_TOL + np.abs(k_a - k_b) + 1.5 * np.abs(t_a - t_b) * np.maximum(k_a, k_b) / (np.e * np.minimum(t_a, t_b))
+    assert np.all(np.abs(maps.res[mask].astype(np.float64) - d["res"][mask]) <= bound)
+    assert np.mean(bound <= 5e-3) >= 0.5  # and for most voxels that bound is RES_TOL-sized: the check bites
 
 
 def test_lbfgsb_size_independent_properties(t2):
@@ -679,6 +760,166 @@ def test_full_size_properties_256cubed(t2):
         assert bool(((x == y) | (x.isnan() & y.isnan())).all()), name
 
 
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configurations at their stated sizes, on the one GPU of this box
+# ---------------------------------------------------------------------------------------------
+def _bitwise_equal(a, b):
+    import torch
+
+    return bool(torch.equal(a, b) or ((a == b) | (a.isnan() & b.isnan())).all())
+
+
+def _subsample_against_oracle(t2, echoes, mask, te, fit, maps, n_sample, seed):
+    """n_sample masked voxels of a device volume against the reference-equivalent oracle and its one-ulp yardstick
+    (spawned pool over the host cores): fraction within 1 ms >= yardstick - 0.01, `success` equal."""
+    import multiprocessing as mp
+
+    import torch
+
+    from oracle.noise_model import perturbed_fit_rows, reference_fit_rows
+
+    idx = torch.nonzero(mask).reshape(-1)
+    pick = idx[torch.randperm(idx.numel(), generator=torch.Generator().manual_seed(seed))[:n_sample].to(idx.device)].sort().values
+    rows = np.ascontiguousarray(echoes[:, pick].t().cpu().numpy())
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    chunks = [c for c in np.array_split(np.arange(len(rows)), cores * 4) if len(c)]
+    with mp.get_context("spawn").Pool(cores) as pool:
+        plain = [r for part in pool.map(reference_fit_rows, [(c, fit, True, True, te, rows) for c in chunks]) for r in part]
+        pert = [r for part in pool.map(perturbed_fit_rows, [(c, fit, True, True, te, rows, 11 + i) for i, c in enumerate(chunks)])
+                for r in part]
+    t2_ref = np.array([r[0][1] for r in plain]).astype(np.float32)
+    t2_pert = np.array([r[0][1] for r in pert]).astype(np.float32)
+    got = maps.t2.reshape(-1)[pick].cpu().numpy()
+    frac = float(np.mean(np.abs(got - t2_ref) <= T2_TOL_MS))
+    yard = float(np.mean(np.abs(t2_pert - t2_ref) <= T2_TOL_MS))
+    assert frac >= yard - 0.01, (fit, frac, yard)
+    if maps.status is not None:
+        ok = maps.status.reshape(-1)[pick].cpu().numpy() == 1
+        assert np.mean(ok == np.array([r[2] for r in plain])) >= 0.999
+    return rows, pick
+
+
+def test_config2_and_config3_adult_brain_at_size(t2):
+    """BASELINE.json configs 2 and 3: adult brain 1 mm reconstruction 256 x 256 x 180 x 6 TE on one GPU.
+    Config 2 ("2-param log-linear fit"): the closed form against its oracle, and the reference's own 2-parameter fit
+    (L-BFGS-B) against the reference-equivalent oracle; config 3 (3-parameter fit with R^2 / CI maps) likewise.
+    At full size: voxel order reversed -> reversed maps bit for bit (different lanes, chunks and queues fit each
+    voxel), two half volumes == the whole volume, zeros outside the mask; on a 20 000-voxel subsample the maps agree
+    with the oracle as well as the oracle agrees with itself under a one-ulp perturbation."""
+    import torch
+
+    from fetal_t2mapping_amd import _abi, synth
+    from oracle import t2fit_oracle as O
+
+    shape = (180, 256, 256)
+    n = shape[0] * shape[1] * shape[2]
+    dev = torch.device("cuda", 0)
+    echoes, mask, te = synth.brain_volume_torch(shape, 6, synth.SEED_BASE + 2, dev)
+    vol = echoes.reshape((6,) + shape)
+    rev_e, rev_m = torch.flip(echoes, dims=[1]).contiguous(), torch.flip(mask, dims=[0]).contiguous()
+    half = n // 2
+    m_bool = mask.bool()
+    for fit, solver in (("gaussian", "loglin"), ("gaussian", "lbfgsb"), ("gaussian_rician", "lbfgsb")):
+        table = t2.fit_table(fit, True)
+        extras = fit == "gaussian_rician"  # config 3 asks for the R^2 / CI maps
+        a = t2.fit_volume(vol, mask, te, fit, table, solver=solver, extras=extras)
+        b = t2.fit_volume(rev_e.reshape((6,) + shape), rev_m, te, fit, table, solver=solver, extras=extras)
+        lo = t2.fit_volume(echoes[:, :half].contiguous().reshape(6, 1, 1, half), mask[:half].contiguous(), te, fit, table,
+                           solver=solver)
+        hi = t2.fit_volume(echoes[:, half:].contiguous().reshape(6, 1, 1, n - half), mask[half:].contiguous(), te, fit, table,
+                           solver=solver)
+        torch.cuda.synchronize()
+        names = ("t2", "k", "sigma", "res") + (("r2", "t2_se", "nit", "status") if extras else ())
+        for name in names:
+            x = getattr(a, name).reshape(-1)
+            assert _bitwise_equal(x, torch.flip(getattr(b, name).reshape(-1), dims=[0])), (fit, solver, name)
+        for name in ("t2", "k", "sigma", "res"):
+            x = getattr(a, name).reshape(-1)
+            assert _bitwise_equal(x[:half], getattr(lo, name).reshape(-1)) and _bitwise_equal(x[half:], getattr(hi, name).reshape(-1))
+            assert bool((x[~m_bool] == 0).all())
+        if solver == "loglin":
+            idx = torch.nonzero(mask).reshape(-1)[:: 7463192 // 20000 or 1][:20000]
+            rows = echoes[:, idx].t().cpu().numpy()
+            want, ok = O.loglinear_fit(rows, te, table, prior=True)
+            assert np.allclose(a.t2.reshape(-1)[idx].cpu().numpy(), want[:, 1], rtol=1e-4)
+            assert np.allclose(a.k.reshape(-1)[idx].cpu().numpy(), want[:, 0], rtol=1e-4)
+        else:
+            _subsample_against_oracle(t2, echoes, mask, te, fit, a, 20000, seed=3)
+        if extras:
+            st = a.status.reshape(-1)
+            assert bool((st[~m_bool] == _abi.ST_MASKED).all()) and float((st[m_bool] == 1).float().mean()) > 0.999
+            r2 = a.r2.reshape(-1)[m_bool]
+            assert bool(torch.isfinite(r2).all()) and float(r2.median()) > 0.9
+            se = a.t2_se.reshape(-1)[m_bool]
+            assert float(torch.isfinite(se).float().mean()) > 0.95
+        del a, b, lo, hi
+
+
+def test_config4_whole_uterus_slabs_equal_whole_volume(t2):
+    """BASELINE.json config 4: 512 x 512 x 360 x 8 TE (94.4 M voxels, 3 GB of samples), the volume that is cut over
+    eight GPUs.  One GPU holds it whole, so the partition can be checked at full size without the other seven: the fit
+    of every one of the eight contiguous slabs (dist.slab_range) and of every one of the eight cyclic shares
+    (dist.cyclic_index, the balanced partition) equals the corresponding voxels of the whole-volume fit bit for bit.
+    (The all-gather that puts the shares together is covered with gloo in tests/test_dist_gloo.py and with RCCL at
+    world size 1 below.)"""
+    import torch
+
+    from fetal_t2mapping_amd import dist as t2dist, synth
+
+    shape = (360, 512, 512)
+    n = shape[0] * shape[1] * shape[2]
+    dev = torch.device("cuda", 0)
+    echoes, mask, te = synth.brain_volume_torch(shape, 8, synth.SEED_BASE + 4, dev)
+    table = t2.fit_table("gaussian_rician", True)
+    whole = t2.fit_volume(echoes.reshape((8,) + shape), mask, te, "gaussian_rician", table)
+    torch.cuda.synchronize()
+    assert bool((whole.t2.reshape(-1)[~mask.bool()] == 0).all())
+    assert t2dist.slab_range(n, 3, 8) == (3 * 45 * 512 * 512, 4 * 45 * 512 * 512)  # whole Z-slabs of 45 slices
+    for r in range(8):
+        lo, hi = t2dist.slab_range(n, r, 8)
+        part = t2.fit_volume(echoes[:, lo:hi].contiguous().reshape(8, 1, 1, hi - lo), mask[lo:hi].contiguous(), te,
+                             "gaussian_rician", table)
+        for name in ("t2", "k", "sigma", "res"):
+            assert _bitwise_equal(getattr(whole, name).reshape(-1)[lo:hi], getattr(part, name).reshape(-1)), (r, name)
+        del part
+    masked_per_rank = []
+    for r in range(8):
+        idx = torch.from_numpy(t2dist.cyclic_index(n, r, 8)).to(dev)
+        assert bool((idx >= 0).all())  # 5760 chunks of 16 Ki voxels: no padding at this size
+        share_m = mask[idx].contiguous()
+        masked_per_rank.append(int(share_m.sum()))
+        part = t2.fit_volume(echoes[:, idx].contiguous().reshape(8, 1, 1, idx.numel()), share_m, te, "gaussian_rician", table)
+        for name in ("t2", "k", "sigma", "res"):
+            assert _bitwise_equal(getattr(whole, name).reshape(-1)[idx], getattr(part, name).reshape(-1)), (r, name)
+        del part, idx
+    assert max(masked_per_rank) / np.mean(masked_per_rank) < 1.03  # the cyclic shares carry equal work
+
+
+def test_config5_streamed_subjects_at_size(t2):
+    """BASELINE.json config 5 (subjects of 256^3 x 8 TE streamed host -> HBM -> host, double-buffered): three subjects
+    through stream.fit_subjects with the reference-trajectory solver == one fit_volume call per subject, bit for bit."""
+    import torch
+
+    from fetal_t2mapping_amd import stream, synth
+
+    shape = (256, 256, 256)
+    dev = torch.device("cuda", 0)
+    table = t2.fit_table("gaussian_rician", True)
+    subs, te = [], None
+    for i in range(3):
+        e, m, te = synth.brain_volume_torch(shape, 8, synth.SEED_BASE + 50 + i, dev)
+        subs.append((e.reshape((8,) + shape).cpu().numpy(), m.reshape(shape).cpu().numpy()))
+        del e, m
+    got = list(stream.fit_subjects(subs, te, "gaussian_rician", table))
+    assert len(got) == 3
+    for (e, m), g in zip(subs, got):
+        want = t2.fit_volume(e, m, te, "gaussian_rician", table)
+        for name in ("t2", "k", "sigma", "res"):
+            assert np.array_equal(getattr(g, name), getattr(want, name), equal_nan=True), name
+        assert np.all(g.t2[m == 0] == 0) and 100.0 < float(np.median(g.t2[m != 0])) < 300.0
+    stream.release()
+
+
 def test_t2_standard_error_map_definition(t2):
     """CI extension (BASELINE.json config 3 asks for CI maps; the reference has none, so this is
     checked against its definition only): se(T2) = sqrt(s^2 [(J^T J)^-1]_T2,T2), s^2 = SS_res/(n - p)."""
@@ -733,6 +974,33 @@ def test_sharded_path_with_rccl_single_rank(t2):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("partition", ["cyclic", "slab"])
+def test_bench_strong_scaling_control_flow_two_ranks_one_gpu(t2, partition):
+    """bench.py's N > 1 path rehearsed on the one GPU of this box (two ranks on cuda:0, gather staged through gloo;
+    the timing means nothing): one volume cut in two shares, each rank fits its share, all-gather, back into voxel
+    order -- and bench.py's own check that the result equals a single-GPU fit of the whole volume bit for bit.  The
+    ragged size (a volume that is not a whole number of chunks) exercises the padding."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    repo = os.path.dirname(os.path.dirname(GOLDEN))
+    env = dict(os.environ, T2FIT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--shape", "37", "96", "100", "--no-also", "--cpu-seconds", "0", "--partition", partition]
+    out = subprocess.run(cmd, check=True, capture_output=True, text=True, env=env, timeout=600, cwd=repo)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["gathered_maps_equal_single_gpu_fit"] is True
+    assert d["config"]["voxels_total"] == 37 * 96 * 100 and d["value"] > 0 and d["fitted_value"] < d["value"]
+
+
 def test_iteration_traces_match_reference_callbacks(t2):
     """fit_voxel's iteration_info (objective value and step length per iteration, what the reference's
     callbacks record at run_t2mapping.py:180-234) against the traces stored in the fixtures."""
@@ -764,6 +1032,50 @@ def test_iteration_traces_match_reference_callbacks(t2):
     d = np.load(os.path.join(GOLDEN, "voxels_lf_gaussian_prior_te8.npz"))
     p, success, n_it, ferr, info = t2.fit_voxel(20, "gaussian", _table(t2, d), d["te"], d["y"], True, False)
     assert len(p) == 2 and isinstance(success, bool) and n_it == len(info) and set(info[0]) == {"f_val", "grad_norm", "step_size"}
+
+
+def test_context_api_through_the_c_abi(t2):
+    """t2fit_create / t2fit_context_volume_host / t2fit_destroy called as a C client would (ctypes, raw pointers): two
+    volumes of different sizes through one context (arena and staging grow, then are reused) equal the device entry
+    point bit for bit, extras included; NULL and bad-device arguments are refused; destroy(NULL) is a no-op."""
+    import ctypes as C
+
+    import torch
+
+    from fetal_t2mapping_amd import _abi, synth
+    from fetal_t2mapping_amd._lib import load
+
+    lib = load()
+    ctx = C.c_void_p()
+    assert lib.t2fit_create(99, C.byref(ctx)) == _abi.E_HIP and not ctx.value
+    assert lib.t2fit_create(0, None) == _abi.E_INVALID
+    assert lib.t2fit_destroy(None) == _abi.OK
+    assert lib.t2fit_create(0, C.byref(ctx)) == _abi.OK and ctx.value
+    table = t2.fit_table("gaussian_rician", True)
+    try:
+        for shape, n_te, seed in (((6, 40, 50), 6, 1), ((3, 100, 5000), 8, 2), ((5, 33, 67), 6, 3)):
+            echoes, mask, te = synth.brain_volume(shape, n_te, seed=seed) if shape[2] < 1000 else \
+                tuple(a.cpu().numpy() if hasattr(a, "cpu") else a for a in synth.brain_volume_torch(shape, n_te, seed, torch.device("cuda", 0)))
+            echoes = np.ascontiguousarray(echoes.reshape((n_te,) + shape), np.float32)
+            mask = np.ascontiguousarray(mask.reshape(shape), np.uint8)
+            n = mask.size
+            cfg = t2.make_config("gaussian_rician", table, te)
+            out = {k: np.empty(n, np.float32) for k in ("t2", "k", "sigma", "res", "r2", "fun", "t2_se")}
+            out["nit"], out["status"] = np.empty(n, np.int32), np.empty(n, np.uint8)
+            maps = _abi.T2FitMaps()
+            for k, a in out.items():
+                setattr(maps, k, a.ctypes.data)
+            assert lib.t2fit_context_volume_host(ctx, C.byref(cfg), echoes.ctypes.data, _abi.LAYOUT_TE_MAJOR, mask.ctypes.data,
+                                                 n, C.byref(maps)) == _abi.OK
+            want = t2.fit_volume(torch.from_numpy(echoes).cuda(), torch.from_numpy(mask).cuda().reshape(-1), te, "gaussian_rician",
+                                 table, extras=True)
+            torch.cuda.synchronize()
+            for k, a in out.items():
+                assert np.array_equal(a, getattr(want, k).reshape(-1).cpu().numpy(), equal_nan=True), (shape, k)
+        assert lib.t2fit_context_volume_host(None, C.byref(cfg), echoes.ctypes.data, 0, None, n, C.byref(maps)) == _abi.E_INVALID
+        assert lib.t2fit_context_volume_host(ctx, C.byref(cfg), None, 0, None, n, C.byref(maps)) == _abi.E_INVALID
+    finally:
+        assert lib.t2fit_destroy(ctx) == _abi.OK
 
 
 def test_host_entry_slab_pipeline_equals_single_piece(t2, monkeypatch):

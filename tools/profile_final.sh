@@ -1,8 +1,8 @@
 # usage (GPU box, repo root): bash tools/profile_final.sh <tag>
-# 1. rocprofv3 --kernel-trace --stats of exactly `python bench.py`; 2. PMC passes (own runs, never combined with a trace)
+# 1. rocprofv3 --kernel-trace --stats of `python bench.py --cpu-seconds 0` (no CPU-baseline worker pool forked under the profiler); 2. PMC passes (own runs, never combined with a trace)
 # for the three fit kernels; 3. the other BASELINE.json configurations; 4. config-5 streaming.
 R=$GRAFT_REPO_ROOT; TAG=$1; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG} -- python3 $R/bench.py > $R/gpurun_out/prof_${TAG}.json 2> $R/gpurun_out/prof_${TAG}.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG} -- python3 $R/bench.py --cpu-seconds 0 > $R/gpurun_out/prof_${TAG}.json 2> $R/gpurun_out/prof_${TAG}.err
 cd $R
 for spec in "lbfgsb:--solver lbfgsb --no-also" "lmf32:--solver lm --precision f32" "loglin:--solver loglin --fit gaussian"; do
   t=${spec%%:*}; args=${spec#*:}
