@@ -1,7 +1,12 @@
 """CLI and volume driver: the reference's ``run_t2mapping.py`` surface on the MI355X fit.
 
     python -m fetal_t2mapping_amd.cli --path /data/qMRI --csv 2024083017_17510000.csv \
-        --in_vivo --gaussian --lf --sim 1 [--TEs 114 202 299] [--no_prior] [--solver lbfgsb|lm|loglin]
+        --in_vivo --gaussian --lf --sim 1 [--TEs 114 202 299] [--no_prior] [--solver lbfgsb|lm|loglin] [--gpus N]
+
+--gpus N (N > 1) starts one process per GPU (torch.distributed.run, RCCL) before anything touches a GPU: with at
+least N subjects in the CSVs each rank streams its own subjects (dist.subjects_of_rank: nothing is exchanged,
+BASELINE.json config 5); with fewer, every volume is cut over the ranks in balanced chunks and the four maps are
+all-gathered (dist.take_cyclic / gather_maps_cyclic, config 4); rank 0 writes the files of a shared volume.
 
 Same flags, metadata CSVs, input/output file names and maps as the reference
 (run_t2mapping.py:483-576, utils/metadata_utils.py, utils/qmri_utils.py:13-33,
@@ -198,6 +203,72 @@ def _fit_subject(vols, masks, keep, te_eff, fit, fit_params, prior, norm, solver
     return mask, out, maps.status.cpu().numpy(), extras
 
 
+def _dist_env():
+    """(rank, world, local_rank) of this process: set by torch.distributed.run, else a single process."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def _fit_share(e_share, m_share, te_eff, fit, fit_params, prior, norm, solver, precision, device):
+    """This rank's share of a volume ((nTE, per) float32, (per,) uint8, host arrays) -> packed maps [4, per] on the GPU
+    (t2, k, sigma, res).  The only function of the sharded path that touches the device."""
+    import ctypes as C
+
+    import torch
+
+    from . import _abi
+    from ._lib import check, require_gpu
+
+    lib = require_gpu()
+    dev = torch.device("cuda", device)
+    with torch.cuda.device(dev):
+        e_d, m_d = torch.from_numpy(e_share).to(dev), torch.from_numpy(m_share).to(dev)
+        per = e_share.shape[1]
+        packed = torch.empty((4, per), dtype=torch.float32, device=dev)
+        cfg = t2map.make_config(fit, fit_params, te_eff, prior, norm, solver, precision)
+        maps = _abi.T2FitMaps()
+        maps.t2, maps.k, maps.sigma, maps.res = (packed[j].data_ptr() for j in range(4))
+        check(lib.t2fit_volume_dev(C.byref(cfg), e_d.data_ptr(), _abi.LAYOUT_TE_MAJOR, m_d.data_ptr(), per, C.byref(maps),
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+    return packed
+
+
+def _fit_subject_sharded(vols, masks, keep, te_eff, fit, fit_params, prior, norm, solver, precision, device):
+    """One (sub, ses) over all ranks (BASELINE.json config 4): union mask on the host (run_t2mapping.py:383-384), this
+    rank's balanced share of the voxels to its GPU, fit, one all-gather of the four maps.  Every rank returns the
+    complete maps; same return shape as _fit_subject (status and extras are not gathered: None)."""
+    import torch.distributed as dist
+
+    from . import dist as t2dist
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    mask = np.zeros(np.asarray(masks[0]).shape, bool)
+    for m in masks:
+        mask |= np.asarray(m) != 0
+    if keep is not None:
+        mask &= keep
+    shape = mask.shape
+    n = mask.size
+    e = np.empty((len(vols), t2dist.cyclic_len(n, world)), np.float32)
+    msh = np.zeros(e.shape[1], np.uint8)
+    flat_mask = mask.reshape(-1)
+    for j, c in enumerate(t2dist.cyclic_chunks(n, rank, world)):  # chunk by chunk: contiguous runs, only this rank's
+        lo = int(c) * t2dist.CHUNK
+        if lo >= n:
+            e[:, j * t2dist.CHUNK:] = 0.0
+            break
+        hi = min(lo + t2dist.CHUNK, n)
+        for i, v in enumerate(vols):
+            e[i, j * t2dist.CHUNK: j * t2dist.CHUNK + hi - lo] = np.asarray(v).reshape(-1)[lo:hi]
+        e[:, j * t2dist.CHUNK + hi - lo: (j + 1) * t2dist.CHUNK] = 0.0
+        msh[j * t2dist.CHUNK: j * t2dist.CHUNK + hi - lo] = flat_mask[lo:hi]
+    packed = _fit_share(e, msh, te_eff, fit, fit_params, prior, norm, solver, precision, device)
+    full = t2dist.gather_maps_cyclic(packed, n).cpu().numpy()
+    out = tuple(np.ascontiguousarray(full[j]).reshape(shape) for j in range(4))
+    status = np.where(flat_mask, np.where(np.isnan(full[0]), 4, 1), 0).astype(np.uint8).reshape(shape)  # NaN maps = infeasible bounds
+    return mask, out, status
+
+
 def process_t2maps(metadata, bids_path, TEs, fit, fit_params, phantom, low_field, prior, fast, norm, sim,
                    solver="lbfgsb", precision="f64", device=0, plots=False, plot_seed=None):
     """run_t2mapping.py:333-479 with the voxel loop on the GPU.  ``plots``: also write the reference's
@@ -205,8 +276,19 @@ def process_t2maps(metadata, bids_path, TEs, fit, fit_params, phantom, low_field
     sitk = _sitk()
     tes_s = [x / 1000 for x in TEs]
     metadata = metadata[metadata["EchoTime"].isin(tes_s)]
+    # more than one process (--gpus N): whole subjects are dealt to the ranks when there are enough of them, otherwise
+    # every volume is shared by all ranks and rank 0 writes its files
+    rank, world, _ = _dist_env()
+    subjects = [(prj, sub, ses) for prj, prj_md in metadata.groupby("prj") for (sub, ses), _ in prj_md.groupby(["sub", "ses"])]
+    share_volumes = world > 1 and len(subjects) < world
+    mine = set(subjects if (world == 1 or share_volumes) else
+               [subjects[i] for i in dist_subjects_of_rank(len(subjects), rank, world)])
+    writer = (rank == 0) or not share_volumes
+    fit_one = _fit_subject_sharded if share_volumes else _fit_subject
     for prj, prj_md in metadata.groupby("prj"):
         for (sub, ses), sub_md in prj_md.groupby(["sub", "ses"]):
+            if (prj, sub, ses) not in mine:
+                continue
             recon_paths, mask_paths, te_eff, label_path = [], [], [], None
             for echotime, acq in sub_md.groupby("EchoTime"):
                 te_eff.append(echotime * 1000)
@@ -224,7 +306,7 @@ def process_t2maps(metadata, bids_path, TEs, fit, fit_params, phantom, low_field
             print(f"TEeffs: {te_eff}")
             print(f"Fitting using {fit} model ... ")
             t0 = time.time()
-            fitted = _fit_subject(vols, masks, keep, te_eff, fit, fit_params, prior, norm, solver, precision, device)
+            fitted = fit_one(vols, masks, keep, te_eff, fit, fit_params, prior, norm, solver, precision, device)
             mask, (t2_map, k_map, sigma_map, res_map), status = fitted[:3]
             print(f"Dimensions of the t2w images: {mask.shape + (te_eff.size,)} (z,y,x,necho)")
             print(f"Mask Dimension: {mask.shape} -  Number of voxels inside mask: {int(np.sum(mask))}")
@@ -234,6 +316,8 @@ def process_t2maps(metadata, bids_path, TEs, fit, fit_params, phantom, low_field
             if n_fail:
                 print(f"FAIL : Optimization failed for {n_fail} voxels")
             print(f"... done. Time to fit: {round(time.time() - t0, 4)} sec")
+            if not writer:
+                continue
             if plots and len(fitted) > 3 and solver != "loglin":  # the closed form has no iterations to plot
                 from . import convergence
 
@@ -248,6 +332,12 @@ def process_t2maps(metadata, bids_path, TEs, fit, fit_params, phantom, low_field
                 id_, gt_ = set_phantom_gt(low_field)
                 save_phantom_csv(t2_map, k_map, sigma_map, label, id_, gt_, bids_path, acq, t2map_dirname, sim, fit,
                                  device=device)
+
+
+def dist_subjects_of_rank(n_subjects, rank, world):
+    from . import dist as t2dist
+
+    return t2dist.subjects_of_rank(n_subjects, rank, world)
 
 
 _EXCLUSIVE_GROUPS = (
@@ -280,7 +370,10 @@ def parse_arguments(argv=None):
                    help="lbfgsb: the reference's solver and stop rules (default); lm: converged bounded LM; "
                         "loglin: closed-form weighted log-linear fit (--gaussian only)")
     p.add_argument("--precision", choices=["f64", "f32"], default="f64", help="arithmetic of the lm solver")
-    p.add_argument("--device", type=int, default=0, help="HIP device ordinal")
+    p.add_argument("--device", type=int, default=0, help="HIP device ordinal (one process; with --gpus each rank uses its own)")
+    p.add_argument("--gpus", type=int, default=1,
+                   help="GPUs of this node to use: N > 1 starts one process per GPU (torch.distributed.run, RCCL); subjects "
+                        "are dealt to the ranks, or, with fewer subjects than ranks, every volume is cut over the ranks")
     p.add_argument("--plots", action="store_true",
                    help="write the reference's convergence-study PNGs (run_t2mapping.py:465-468) under "
                         "<prj>/ada/convergence_analysis; off by default, the reference always draws them")
@@ -288,9 +381,41 @@ def parse_arguments(argv=None):
     return p.parse_args(argv)
 
 
+def _relaunch_per_gpu(args, argv):
+    """--gpus N from a plain invocation: start N ranks of this module under torch.distributed.run as a child process
+    and leave with its exit code.  Runs before anything has touched a GPU (a process that has initialised HIP must not
+    spawn the ranks' parent on this platform, and needs no device itself)."""
+    import socket
+    import subprocess
+
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "fetal_t2mapping_amd.cli",
+           *(list(argv) if argv is not None else sys.argv[1:])]
+    raise SystemExit(subprocess.call(cmd))
+
+
 def main(argv=None):
     """run_t2mapping.py:522-576."""
     args = parse_arguments(argv)
+    rank, world, local_rank = _dist_env()
+    if args.gpus > 1 and world == 1:
+        _relaunch_per_gpu(args, argv)
+    if world > 1:  # a rank started by torch.distributed.run: its own GPU, one process group for the node
+        import torch
+        import torch.distributed as dist
+
+        backend = os.environ.get("T2FIT_CLI_BACKEND", "nccl")  # "gloo": rehearsal of the control flow without RCCL
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            args.device = local_rank
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if not os.path.exists(args.path):
         print(f"Error: The specified path does not exist: {args.path}")
         raise SystemExit(1)
@@ -304,9 +429,17 @@ def main(argv=None):
         print("Warning: Fitting using normalization is not optimal !")
     fit, fit_params = t2map.set_fit_params(args)
     metadata = set_metadata(csv_path, args.csv, low_field)
-    process_t2maps(metadata, bids_path, TEs, fit, fit_params, phantom, low_field, not args.no_prior, fast,
-                   bool(args.norm), args.sim, solver=args.solver, precision=args.precision, device=args.device,
-                   plots=args.plots, plot_seed=args.plot_seed)
+    try:
+        process_t2maps(metadata, bids_path, TEs, fit, fit_params, phantom, low_field, not args.no_prior, fast,
+                       bool(args.norm), args.sim, solver=args.solver, precision=args.precision, device=args.device,
+                       plots=args.plots, plot_seed=args.plot_seed)
+    finally:
+        if world > 1:
+            import torch.distributed as dist
+
+            if dist.is_initialized():
+                dist.barrier()
+                dist.destroy_process_group()
 
 
 if __name__ == "__main__":

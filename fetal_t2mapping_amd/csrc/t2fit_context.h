@@ -40,17 +40,22 @@ class CopyPool {
   }
   int size() const { return (int)workers_.size(); }
 
-  // A batch of row copies (dst, src, bytes), each row cut into pieces of <= 4 MiB; returns when all are done.
+  // A batch of row copies (dst, src, bytes; src == nullptr: zero-fill), each row cut into pieces of <= 4 MiB; returns
+  // when all are done.
   struct Row { void* dst; const void* src; size_t bytes; };
+  static void move(const Row& p) {
+    if (p.src) std::memcpy(p.dst, p.src, p.bytes);
+    else std::memset(p.dst, 0, p.bytes);
+  }
   void copy(const std::vector<Row>& rows) {
     constexpr size_t kPiece = (size_t)4 << 20;
     std::vector<Row> pieces;
     for (const Row& r : rows)
       for (size_t off = 0; off < r.bytes; off += kPiece)
-        pieces.push_back(Row{(char*)r.dst + off, (const char*)r.src + off, std::min(kPiece, r.bytes - off)});
+        pieces.push_back(Row{(char*)r.dst + off, r.src ? (const char*)r.src + off : nullptr, std::min(kPiece, r.bytes - off)});
     if (pieces.empty()) return;
     if (pieces.size() == 1 || workers_.empty()) {
-      for (const Row& p : pieces) std::memcpy(p.dst, p.src, p.bytes);
+      for (const Row& p : pieces) move(p);
       return;
     }
     std::unique_lock<std::mutex> g(m_);
@@ -73,7 +78,7 @@ class CopyPool {
       while (batch_ && next_ < batch_->size()) {
         const Row p = (*batch_)[next_++];
         g.unlock();
-        std::memcpy(p.dst, p.src, p.bytes);
+        move(p);
         g.lock();
         if (--left_ == 0) done_cv_.notify_all();
       }

@@ -999,16 +999,22 @@ int t2fit_context_volume_host(t2fit_context* c, const t2fit_config* cfg, const f
   std::lock_guard<std::mutex> guard(c->busy);
   T2_HIP(hipSetDevice(c->device));
   const int n_te = cfg->n_te;
-  // Slabs of about 2.2 M voxels (multiples of 4096, so that every slab keeps the alignment the vectorised kernels
+  // Slabs of about 2.4 M voxels (multiples of 4096, so that every slab keeps the alignment the vectorised kernels
   // want and stays on the large-volume kernels): short enough that filling and draining the pipeline costs little,
-  // long enough that a slab's fit covers the host-side copies of its neighbours.
+  // long enough that a slab's fit covers the host-side copies of its neighbours.  The first slab is a quarter of
+  // that: the device starts working after a quarter of the copy time.
   int64_t slab = (int64_t)9 << 18;  // 2,359,296
-  if (const char* e = std::getenv("T2FIT_HOST_SLABS")) {  // A/B switch and tests: number of slabs
+  bool graded = true;
+  if (const char* e = std::getenv("T2FIT_HOST_SLABS")) {  // A/B switch and tests: number of (equal) slabs
     const int64_t want = std::max(1, std::min(4096, std::atoi(e)));
     slab = (n_vox + want - 1) / want;
+    graded = false;
   }
   slab = std::max<int64_t>(4096, (slab + 4095) & ~(int64_t)4095);
-  const int n_slabs = (int)((n_vox + slab - 1) / slab);
+  std::vector<int64_t> bounds{0};
+  if (graded && n_vox > slab) bounds.push_back(std::max<int64_t>(4096, (slab / 4) & ~(int64_t)4095));
+  while (bounds.back() < n_vox) bounds.push_back(std::min<int64_t>(n_vox, bounds.back() + slab));
+  const int n_slabs = (int)bounds.size() - 1;
   // outputs: float maps (t2, k, sigma, res, r2, fun, t2_se), then nit (int32), then status (uint8)
   float* host_f[7] = {maps->t2, maps->k, maps->sigma, maps->res, maps->r2, maps->fun, maps->t2_se};
   const size_t slab_in = (size_t)slab * n_te * 4 + (size_t)slab;          // samples + mask bytes of one slab
@@ -1064,7 +1070,34 @@ int t2fit_context_volume_host(t2fit_context* c, const t2fit_config* cfg, const f
   float* fm[7];
   for (int j = 0; j < 7; ++j) fm[j] = (float*)(buf + off_maps + j * map_b);
   const bool want[7] = {true, true, true, true, maps->r2 != nullptr, maps->fun != nullptr, maps->t2_se != nullptr};
-  auto span = [&](int k, int64_t& lo, int64_t& len) { lo = (int64_t)k * slab; len = std::min<int64_t>(slab, n_vox - lo); };
+  auto span = [&](int k, int64_t& lo, int64_t& len) { lo = bounds[k]; len = bounds[k + 1] - lo; };
+  // Blocks of 4096 voxels without a single voxel in the mask are neither copied in (the kernels never read the samples
+  // of a masked-out voxel) nor copied out (their maps are zeros: written here, not fetched): on a brain mask that is
+  // half of the host-side copy traffic, which is what bounds this entry point.  runs[k]: the [start, end) voxel
+  // ranges of slab k, relative to its start, that do hold masked voxels.
+  constexpr int64_t kBlockVox = 4096;
+  std::vector<std::vector<std::pair<int64_t, int64_t>>> runs(n_slabs);
+  auto find_runs = [&](int k) {
+    int64_t lo, len;
+    span(k, lo, len);
+    auto& r = runs[k];
+    if (!mask) { r.emplace_back(0, len); return; }
+    for (int64_t b = 0; b < len; b += kBlockVox) {
+      const int64_t e = std::min(len, b + kBlockVox);
+      const uint8_t* p = mask + lo + b;
+      bool any = false;
+      int64_t i = 0;
+      for (; i + 8 <= e - b && !any; i += 8) {
+        uint64_t w;
+        std::memcpy(&w, p + i, 8);
+        any = w != 0;
+      }
+      for (; i < e - b && !any; ++i) any = p[i] != 0;
+      if (!any) continue;
+      if (!r.empty() && r.back().second == b) r.back().second = e;
+      else r.emplace_back(b, e);
+    }
+  };
   // device -> pinned: the maps of slab k, packed one after the other in its staging slot
   auto queue_d2h = [&](int k) -> hipError_t {
     int64_t lo, len;
@@ -1088,10 +1121,20 @@ int t2fit_context_volume_host(t2fit_context* c, const t2fit_config* cfg, const f
     const char* src = c->pin_out[k & 1];
     std::vector<t2fit::CopyPool::Row> rows;
     size_t off = 0;
+    auto add = [&](char* dst, size_t elem) {  // one map of this slab: copy the runs, zero the gaps (src == nullptr)
+      int64_t at = 0;
+      for (const auto& r : runs[k]) {
+        if (r.first > at) rows.push_back({dst + at * elem, nullptr, (size_t)(r.first - at) * elem});
+        rows.push_back({dst + r.first * elem, src + off + r.first * elem, (size_t)(r.second - r.first) * elem});
+        at = r.second;
+      }
+      if (at < len) rows.push_back({dst + at * elem, nullptr, (size_t)(len - at) * elem});
+      off += (size_t)len * elem;
+    };
     for (int j = 0; j < 7; ++j)
-      if (want[j]) { rows.push_back({host_f[j] + lo, src + off, (size_t)len * 4}); off += (size_t)len * 4; }
-    if (maps->nit) { rows.push_back({maps->nit + lo, src + off, (size_t)len * 4}); off += (size_t)len * 4; }
-    if (maps->status) rows.push_back({maps->status + lo, src + off, (size_t)len});
+      if (want[j]) add((char*)(host_f[j] + lo), 4);
+    if (maps->nit) add((char*)(maps->nit + lo), 4);
+    if (maps->status) add((char*)(maps->status + lo), 1);  // T2FIT_ST_MASKED == 0
     c->pool->copy(rows);
     return hipSuccess;
   };
@@ -1100,11 +1143,16 @@ int t2fit_context_volume_host(t2fit_context* c, const t2fit_config* cfg, const f
     span(k, lo, len);
     char* stage = c->pin_in[k & 1];
     if (k >= 2) T2_HIP_C(hipEventSynchronize(ev_in[k - 2]));  // the DMA out of this slot has finished
+    find_runs(k);
     std::vector<t2fit::CopyPool::Row> rows;
-    if (layout == T2FIT_LAYOUT_TE_MAJOR) {  // n_te rows of `len` samples out of planes of n_vox
-      for (int i = 0; i < n_te; ++i) rows.push_back({stage + (size_t)i * len * 4, echoes + (size_t)i * n_vox + lo, (size_t)len * 4});
-    } else {
-      rows.push_back({stage, echoes + (size_t)lo * n_te, (size_t)len * n_te * 4});
+    for (const auto& r : runs[k]) {
+      const size_t nb = (size_t)(r.second - r.first);
+      if (layout == T2FIT_LAYOUT_TE_MAJOR) {  // n_te rows of `len` samples out of planes of n_vox
+        for (int i = 0; i < n_te; ++i)
+          rows.push_back({stage + ((size_t)i * len + r.first) * 4, echoes + (size_t)i * n_vox + lo + r.first, nb * 4});
+      } else {
+        rows.push_back({stage + (size_t)r.first * n_te * 4, echoes + (size_t)(lo + r.first) * n_te, nb * n_te * 4});
+      }
     }
     if (mask) rows.push_back({stage + (size_t)len * n_te * 4, mask + lo, (size_t)len});
     c->pool->copy(rows);

@@ -144,3 +144,84 @@ def test_subject_round_robin_covers_every_subject_once(monkeypatch):
 
     got = list(t2dist.fit_subjects_round_robin(load, 10, [1.0, 2.0], "gaussian", {}, rank=1, world=4))
     assert got == [(1, 2.0), (5, 10.0), (9, 18.0)] and loaded == [1, 5, 9]
+
+
+# ---- the CLI's --gpus control flow (fetal_t2mapping_amd/cli.py) with gloo, the GPU fit replaced by a stand-in -------
+def _cli_fake_share(e_share, m_share, te_eff, fit, fit_params, prior, norm, solver, precision, device):
+    return torch.from_numpy(_fake_fit(e_share, m_share))
+
+
+def _cli_fake_subject(vols, masks, keep, te_eff, fit, fit_params, prior, norm, solver, precision, device):
+    e = np.stack([np.asarray(v, np.float32).reshape(-1) for v in vols])
+    mask = np.zeros(np.asarray(masks[0]).shape, bool)
+    for m in masks:
+        mask |= np.asarray(m) != 0
+    out = _fake_fit(e, mask.reshape(-1).astype(np.uint8))
+    return mask, tuple(o.reshape(mask.shape) for o in out), np.where(mask, 1, 0).astype(np.uint8)
+
+
+def _cli_worker(rank, world, port, root, n_subjects, out):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fake_sitk
+
+    from fetal_t2mapping_amd import cli as R
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), T2FIT_CLI_BACKEND="gloo")
+    sitk = fake_sitk.install()
+    R._fit_share = _cli_fake_share
+    R._fit_subject = _cli_fake_subject
+    R.main(["--path", root, "--csv", "log.csv", "--in_vivo", "--gaussian", "--lf", "--sim", "d1", "--TEs", "114", "202", "299",
+            "--gpus", str(world)])
+    out[rank] = {os.path.relpath(p, root): np.array(img.arr) for p, img in sitk.written.items()}
+
+
+def _cli_tree(tmp_path, n_subjects, shape):
+    import pandas as pd
+
+    from fetal_t2mapping_amd import cli as R
+
+    root = str(tmp_path)
+    bids = os.path.join(root, "projects") + "/"
+    os.makedirs(os.path.join(bids, "prj-950"))
+    os.makedirs(os.path.join(root, "dicom", "logs"))
+    rng = np.random.default_rng(9)
+    rows, data = [], {}
+    for s in range(n_subjects):
+        vols = rng.normal(100.0, 10.0, size=(3,) + shape).astype(np.float32)
+        mask = (rng.random(shape) < 0.5).astype(np.uint8)
+        data[f"sub-{s + 1:03d}"] = (vols, mask)
+        for i, t in enumerate((114, 202, 299)):
+            acq = {"prj": "prj-950", "sub": f"sub-{s + 1:03d}", "ses": "ses-01", "run": f"run-{i + 1:02d}", "EchoTime": t / 1000.0,
+                   "CoilString": "HeadNeck"}
+            rows.append(acq)
+            np.save(R.get_img_path(bids, acq, R.recon_dirname).replace(" ", "") + ".npy", vols[i])
+            np.save(R.get_img_path(bids, acq, R.mask_dirname).replace(" ", "") + ".npy", mask)
+    pd.DataFrame(rows).to_csv(os.path.join(root, "dicom", "logs", "log.csv"), index=False)
+    return root, data
+
+
+@pytest.mark.parametrize("n_subjects", [1, 3])
+def test_cli_gpus_control_flow_two_ranks(tmp_path, n_subjects):
+    """`--gpus 2` as torch.distributed.run would start it (two ranks, gloo instead of RCCL, the fit a per-voxel
+    stand-in).  One subject: the volume is cut over the ranks in hash-dealt chunks, the maps are all-gathered and
+    rank 0 alone writes the four files, equal to the stand-in applied to the whole volume.  Three subjects: they are
+    dealt to the ranks (0 and 2 to rank 0, 1 to rank 1), nothing is exchanged, each rank writes its own files."""
+    root, data = _cli_tree(tmp_path, n_subjects, (3, 40, 300))  # 36 000 voxels: three chunks, the last one ragged
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_cli_worker, args=(2, _free_port(), root, n_subjects, out), nprocs=2, join=True)
+    written = {**out[0], **out[1]}
+    if n_subjects == 1:
+        assert len(out[0]) == 4 and len(out[1]) == 0
+    else:
+        assert len(out[0]) == 8 and len(out[1]) == 4
+        assert all("sub-002" in p for p in out[1]) and not any("sub-002" in p for p in out[0])
+    for sub, (vols, mask) in data.items():
+        want = _fake_fit(vols.reshape(3, -1), mask.reshape(-1))
+        for j, tag in enumerate(("t2", "k", "sigma", "res")):
+            key = [p for p in written if sub in p and f"_{tag}map_" in p]
+            assert len(key) == 1, (sub, tag, list(written))
+            assert np.array_equal(written[key[0]].reshape(-1), want[j]), (sub, tag)
