@@ -95,9 +95,12 @@ def parse():
     p.add_argument("--no-gather", action="store_true", help="skip the all-gather of the maps (N > 1)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration (0 = skip)")
     p.add_argument("--no-also", action="store_true", help="skip the secondary (converged LM float32) measurement")
-    p.add_argument("--reserve-cus", type=int, default=0,
-                   help="N > 1 with the all-gather: CUs the persistent fit kernel leaves free for RCCL's kernels (A/B "
-                        "switch; off by default: no RCCL run has shown that it pays)")
+    p.add_argument("--reserve-cus", type=int, default=8,
+                   help="N > 1 with the all-gather: CUs the persistent fit kernel leaves free for RCCL's kernels (0 = none). "
+                        "Measured on one GPU (profiles/r02_overlap_*.jsonl): kernels that need little LDS run beside the fit "
+                        "even with no CU left free, but the fit's workgroups hold 153 of a CU's 160 KiB of LDS, which a "
+                        "collective's kernel does not fit beside; 8 free CUs cost the fit 3 %% and are a bet, not a measurement "
+                        "(no multi-GPU node was available to the build)")
     return p.parse_args()
 
 

@@ -459,6 +459,9 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
             *c.trace_n = 0;
           }
           A::init(s, c, box_x0, lb, ub, hist);
+#if defined(T2_PHASE_STAMPS)
+          if constexpr (A::kSplit) s.diag = diag;
+#endif
         }
       }
       T2_BLK_END(c, 8, t_rf)
@@ -865,7 +868,7 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
     unsigned long long h[kCounterWords];
     T2_HIP(hipMemcpyAsync(h, counter, sizeof(h), hipMemcpyDeviceToHost, st));
     T2_HIP(hipStreamSynchronize(st));
-    static const char* names[kDiagBlocks] = {"digest: ls tests", "digest: dcstep", "digest: new iterate", "begin: build_b",
+    static const char* names[kDiagBlocks] = {"eval + digest", "cauchy: breakpoint taken", "subsm: projected", "begin: build_b",
                                              "begin: cauchy", "begin: subsm", "begin: ls set-up", "eval", "refill",
                                              "begin (all)", "wave life"};
     const double life = (double)h[16 + 3 * 10];

@@ -292,6 +292,9 @@ T2_HD double t2_div_by_rcp(double a, double b, double r) {
 
 // Mean signed residual from the float32 maps (utils/t2map_utils.py:62-89): float64 prediction
 // stored as float32, float32 residuals, numpy's pairwise float32 row sum, divided by nTE.
+// This is the arithmetic of numpy >= 2 (NEP 50: the np.float64 echo time promotes the prediction to float64), which
+// the fixtures were generated with; the reference's frozen numpy 1.26 would evaluate the prediction in float32
+// (about 1e-4 absolute difference: parity with that environment is unpinned, tests/golden/README.md).
 T2_HD float residual_mean(const ObjCtx& c, float k32, float t232, float s32) {
   const int n = c.P->n_te;
   const bool gauss = c.P->model == T2FIT_MODEL_GAUSSIAN;

@@ -318,6 +318,9 @@ struct Lbfgsb {
   uint8_t status;
   bool first;
   bool wn_stale;  // the library's WN1 matrix would be out of date (see begin())
+#if defined(T2_PHASE_STAMPS)
+  unsigned long long* diag = nullptr;  // diagnostic build: the wave's block counters, for the const helpers
+#endif
 #if !defined(__HIPCC__)
   int n_reset = 0;  // host simulator only (debugging aid): how often the correction memory was dropped
 #define T2_COUNT_RESET() ++n_reset
@@ -570,6 +573,8 @@ struct Lbfgsb {
       tj = tmin;
       const double dt = tj - tj0;
       if (dtm < dt) break;
+      T2_BLK_T0(t_bp)
+      T2_BLK_END((*this), 1, t_bp)
       tsum += dt;
       --nleft;
       double dibp = 0.0;
@@ -658,6 +663,8 @@ struct Lbfgsb {
       }
     }
     if (!projected) return true;
+    T2_BLK_T0(t_pj)
+    T2_BLK_END((*this), 2, t_pj)
     double ddp = 0.0;
     T2_UNROLL
     for (int i = 0; i < N; ++i) ddp = fma(z[i] - x[i], g[i], ddp);

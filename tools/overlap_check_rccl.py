@@ -62,12 +62,16 @@ torch.cuda.synchronize()
 alone = t0.elapsed_time(t1)
 # the gather started right behind the launch of a fit
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+side = torch.cuda.Stream()
 ev[0].record(sa)
 fit()
 ev[1].record(sa)
-w = dist.all_gather_into_tensor(gathered.view(-1), prev.view(-1), async_op=True)  # RCCL's own stream
-side = torch.cuda.Stream()
+# The collective is issued with `side` as the current stream: torch makes RCCL's stream wait for the CURRENT stream
+# (that is how bench.py's gather of step i waits for fit i); issued from the compute stream it would simply queue
+# behind the fit just launched.  Here the gather's input does not depend on that fit, as in bench.py where
+# gather i runs beside fit i+1.
 with torch.cuda.stream(side):
+    w = dist.all_gather_into_tensor(gathered.view(-1), prev.view(-1), async_op=True)  # RCCL's own stream
     w.wait()          # stream-side wait on `side`, not on the compute stream
     ev[2].record(side)
 torch.cuda.synchronize()
