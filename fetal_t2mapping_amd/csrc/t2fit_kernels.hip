@@ -486,11 +486,13 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
       const unsigned long long pb = __ballot(parked);
       if (pb != 0ull && (__popcll(pb) >= park_min || __ballot(busy && !parked) == 0ull)) {
         if (parked) {
-          parked = false;
           T2_BLK_T0(t_bg)
-          const bool ended = s.begin(c, pend);
+          pend = s.begin_pass(c, pend);
           T2_BLK_END(c, 9, t_bg)
-          if (ended) { busy = false; done = true; }
+          // GO_BEGIN / GO_FAIL: the iteration has to be begun again (memory dropped, line search could not start):
+          // the lane stays parked and comes back here in the next round
+          if (pend == A::Solver::GO_DONE) { parked = false; busy = false; done = true; }
+          else if (pend == A::Solver::GO_TRIAL) parked = false;
         }
       }
     } else {

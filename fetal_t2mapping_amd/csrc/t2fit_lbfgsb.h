@@ -828,101 +828,100 @@ struct Lbfgsb {
     for (int i = 0; i < N; ++i) x[i] = stp == 1.0 ? z[i] : stp * d[i] + t[i];
   }
 
-  // `next` is GO_BEGIN or GO_FAIL (what digest() returned).  Returns true when the fit has ended, false when `x`
-  // holds the next point to evaluate.
-  T2_HD bool begin(const ObjCtx& c, int next) {
+  // One pass of the begin-iteration work.  `next` is GO_BEGIN or GO_FAIL (what digest() or an earlier pass returned).
+  // Returns GO_TRIAL (`x` holds the next point to evaluate), GO_DONE (the fit has ended), or GO_BEGIN / GO_FAIL: the
+  // memory was dropped or the line search could not start, and the iteration has to be begun again -- by another
+  // call.  There is deliberately no loop in here: the restarts are rare (none on a typical --prior volume, one per
+  // 15 voxels under --no_prior), and a back-edge around B / Cauchy point / subspace step cost 7 % of the kernel in
+  // scalar-register spills alone; the persistent kernel simply calls again in its next round.
+  T2_HD int begin_pass(const ObjCtx& c, int next) {
     const LaneParams& P = *c.P;
-    for (;;) {
-      if (next == GO_FAIL) {
-        // line search could not be completed: back to the previous iterate.  With an empty memory
-        // that is scipy's ABNORMAL termination (success False); otherwise drop the memory and redo.
-        T2_UNROLL
-        for (int i = 0; i < N; ++i) { x[i] = t[i]; g[i] = r[i]; }
-        f = fold;
-        next = GO_DONE;
-        if (col != 0) { col = 0; theta = 1.0; wn_stale = false; next = GO_BEGIN; T2_COUNT_RESET(); }
-      }
-      if (next != GO_BEGIN) break;
-      double B[N][N];
-      T2_BLK_T0(t_b)
-      build_b(B);
-      T2_BLK_END(c, 3, t_b)
-      T2_BLK_T0(t_c)
-      cauchy(x, g, B, theta, sbgnrm, iwhere, z);
-      T2_BLK_END(c, 4, t_c)
-      int nfree = 0;
+    if (next == GO_FAIL) {
+      // line search could not be completed: back to the previous iterate.  With an empty memory
+      // that is scipy's ABNORMAL termination (success False); otherwise drop the memory and redo.
       T2_UNROLL
-      for (int i = 0; i < N; ++i) nfree += iwhere[i] <= 0;
-      if (nfree != 0 && col != 0) {
-        if (wn_stale) {
-          // The library keeps its 2m x 2m matrix WN1 (inner products of the pairs over the free and the active
-          // variables) up to date inside formk, which it only calls when a subspace step is taken.  An iteration
-          // whose Cauchy point leaves no variable free skips formk, so the changes of that iteration (the newest
-          // pair, the variables that left the free set) never reach WN1; at the next iteration that takes a
-          // subspace step the factorisation of the then inconsistent matrix fails ("nonpositive definiteness in
-          // Cholesky factorization in formk") and the library drops its memory and restarts the iteration.  This
-          // is deterministic and frequent when bounds are active (5-8 % of the voxels of a --no_prior fit; all
-          // 150 restarts the reference makes on the golden fixtures follow this rule, none is missed by it), so it
-          // is part of the reference's trajectory and is restated here, without the matrix: a flag.
-          wn_stale = false;
-          col = 0; theta = 1.0;
-          T2_COUNT_RESET();
-          continue;
-        }
+      for (int i = 0; i < N; ++i) { x[i] = t[i]; g[i] = r[i]; }
+      f = fold;
+      if (col == 0) return GO_DONE;
+      col = 0; theta = 1.0; wn_stale = false;
+      T2_COUNT_RESET();
+    }
+    double B[N][N];
+    T2_BLK_T0(t_b)
+    build_b(B);
+    T2_BLK_END(c, 3, t_b)
+    T2_BLK_T0(t_c)
+    cauchy(x, g, B, theta, sbgnrm, iwhere, z);
+    T2_BLK_END(c, 4, t_c)
+    int nfree = 0;
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) nfree += iwhere[i] <= 0;
+    // Two reasons to drop the memory and begin the iteration again.  (a) The reduced matrix of the subspace step is
+    // not positive definite (numerical breakdown).  (b) The library's stale WN1: it keeps its 2m x 2m matrix WN1
+    // (inner products of the pairs over the free and the active variables) up to date inside formk, which it only
+    // calls when a subspace step is taken.  An iteration whose Cauchy point leaves no variable free skips formk, so
+    // the changes of that iteration (the newest pair, the variables that left the free set) never reach WN1; at the
+    // next iteration that takes a subspace step the factorisation of the then inconsistent matrix fails
+    // ("nonpositive definiteness in Cholesky factorization in formk") and the library drops its memory and
+    // restarts the iteration.  This is deterministic and frequent when bounds are active (5-8 % of the voxels of a
+    // --no_prior fit; all 150 restarts the reference makes on the golden fixtures follow this rule, none is missed
+    // by it), so it is part of the reference's trajectory and is restated here, without the matrix: a flag.
+    bool restart = false;
+    if (nfree != 0 && col != 0) {
+      restart = wn_stale;
+      if (!restart) {
         T2_BLK_T0(t_s)
-        const bool ok = subsm(x, g, B, iwhere, z);
+        restart = !subsm(x, g, B, iwhere, z);
         T2_BLK_END(c, 5, t_s)
-        if (!ok) {  // numerical breakdown: drop the memory, redo the iteration
-          col = 0; theta = 1.0;
-          T2_COUNT_RESET();
-          continue;
-        }
-      } else if (col != 0) {
-        wn_stale = true;  // no variable is free at the Cauchy point: the library skips formk (see above)
       }
-      T2_BLK_T0(t_l)
-      // line search along d = z - x (lnsrlb)
+    } else if (col != 0) {
+      wn_stale = true;  // no variable is free at the Cauchy point: the library skips formk
+    }
+    if (restart) {
+      wn_stale = false;
+      col = 0; theta = 1.0;
+      T2_COUNT_RESET();
+      return GO_BEGIN;
+    }
+    T2_BLK_T0(t_l)
+    // line search along d = z - x (lnsrlb)
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) { d[i] = z[i] - x[i]; t[i] = x[i]; r[i] = g[i]; }
+    stpmx = 1e10;
+    if (nit == 0) {
+      stpmx = 1.0;
+    } else {
       T2_UNROLL
-      for (int i = 0; i < N; ++i) { d[i] = z[i] - x[i]; t[i] = x[i]; r[i] = g[i]; }
-      stpmx = 1e10;
-      if (nit == 0) {
-        stpmx = 1.0;
-      } else {
-        T2_UNROLL
-        for (int i = 0; i < N; ++i) {
-          const double a1 = d[i];
-          if (a1 != 0.0) {  // lower bound limits a decreasing variable, upper bound an increasing one
-            const double a2 = (a1 < 0.0 ? lb[i] : ub[i]) - x[i];
-            const bool at_bound = a1 < 0.0 ? a2 >= 0.0 : a2 <= 0.0;
-            const bool limits = a1 < 0.0 ? a1 * stpmx < a2 : a1 * stpmx > a2;
-            if (at_bound) stpmx = 0.0;
-            else if (limits) stpmx = t2_fdiv(a2, a1);
-          }
+      for (int i = 0; i < N; ++i) {
+        const double a1 = d[i];
+        if (a1 != 0.0) {  // lower bound limits a decreasing variable, upper bound an increasing one
+          const double a2 = (a1 < 0.0 ? lb[i] : ub[i]) - x[i];
+          const bool at_bound = a1 < 0.0 ? a2 >= 0.0 : a2 <= 0.0;
+          const bool limits = a1 < 0.0 ? a1 * stpmx < a2 : a1 * stpmx > a2;
+          if (at_bound) stpmx = 0.0;
+          else if (limits) stpmx = t2_fdiv(a2, a1);
         }
       }
-      stp = 1.0;  // every variable is boxed, so the first step is not rescaled by 1/|d|
-      fold = f;
-      gd = 0.0;
-      T2_UNROLL
-      for (int i = 0; i < N; ++i) gd += g[i] * d[i];
-      gdold = gd;
-      dcsrch_start(f, gd, stp, 1e-3, 0.0, stpmx, ls);  // ERROR also covers gd >= 0: not a descent direction
-      ifun = 1;
-      next = (ls.task != LS_FG || ifun - 1 >= P.maxls) ? GO_FAIL : GO_TRIAL;
-      T2_BLK_END(c, 6, t_l)
     }
-    if (next == GO_TRIAL) {
-      set_trial();
-      return false;
-    }
-    return true;
+    stp = 1.0;  // every variable is boxed, so the first step is not rescaled by 1/|d|
+    fold = f;
+    gd = 0.0;
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) gd += g[i] * d[i];
+    gdold = gd;
+    dcsrch_start(f, gd, stp, 1e-3, 0.0, stpmx, ls);  // ERROR also covers gd >= 0: not a descent direction
+    ifun = 1;
+    T2_BLK_END(c, 6, t_l)
+    if (ls.task != LS_FG || ifun - 1 >= P.maxls) return GO_FAIL;
+    set_trial();
+    return GO_TRIAL;
   }
 
+  // everything between two evaluations: true when the fit has ended, false when `x` holds the next point to evaluate
   T2_HD bool advance(const ObjCtx& c) {
-    const int next = digest(c);
-    if (next == GO_TRIAL) return false;
-    if (next == GO_DONE) return true;
-    return begin(c, next);
+    int next = digest(c);
+    while (next == GO_BEGIN || next == GO_FAIL) next = begin_pass(c, next);
+    return next == GO_DONE;
   }
 
   T2_HD void result(LaneResult& out) const {
