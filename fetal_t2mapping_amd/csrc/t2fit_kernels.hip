@@ -290,6 +290,7 @@ constexpr int kCounterWords = 16 + kDiagWords;                  // chunk counter
 template <int MODEL, int NTE = 0> struct LbfgsbLane {
   using Solver = Lbfgsb<MODEL, NTE>;
   static constexpr int NP = Solver::N;
+  static constexpr int kNte = NTE;  // > 0: the echo count is a compile-time constant (the refill loops flatten too)
   static constexpr int kHistDoubles = 2 * Solver::M * Solver::N;  // correction pairs, per lane, in LDS
   static constexpr int kWavesPerSimd = 1;
   static constexpr int kRefillMin = 8;   // measured on MI355X: 1 -> 28.1 ms, 8 -> 26.8 ms, 16 -> 27.6 ms
@@ -301,6 +302,7 @@ template <int MODEL, int NTE = 0> struct LbfgsbLane {
 template <typename T, int NPAR> struct LmLaneAdaptor {
   using Solver = LmLane<T, NPAR>;
   static constexpr int NP = NPAR;
+  static constexpr int kNte = 0;
   static constexpr int kHistDoubles = 0;
   static constexpr int kWavesPerSimd = sizeof(T) == 4 ? 4 : 1;
   static constexpr int kRefillMin = 24;  // measured (f32, 3 parameters, MI355X): 8 -> 1.62 ms, 16 -> 1.42 ms, 24 -> 1.35 ms, 32 -> 1.35 ms
@@ -408,7 +410,7 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
         // column (already divided by the row maximum when cfg.norm, run_t2mapping.py:237-238)
         bool finite = true;
         float ymax = 0.0f, y0 = 0.0f;
-        const int n_te = P.n_te;
+        const int n_te = A::kNte > 0 ? A::kNte : P.n_te;
         for (int i0 = 0; i0 < n_te; i0 += 8) {
           float tmp[8];
 #pragma unroll

@@ -203,7 +203,7 @@ T2_HD void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy, 
 // START call of dcsrch: validates the first step and initialises the search state.
 T2_HD void dcsrch_start(double f, double g, double stp, double ftol, double stpmin, double stpmax, LsState& s) {
   const double xtrapu = 4.0;
-  if (stp < stpmin || stp > stpmax || g >= 0.0) { s.task = LS_ERROR; return; }
+  const bool bad = stp < stpmin || stp > stpmax || g >= 0.0;  // (the state below is dead after an error)
   s.brackt = false;
   s.stage = 1;
   s.finit = f; s.ginit = g; s.gtest = ftol * s.ginit;
@@ -211,7 +211,7 @@ T2_HD void dcsrch_start(double f, double g, double stp, double ftol, double stpm
   s.stx = 0.0; s.fx = s.finit; s.gx = s.ginit;
   s.sty = 0.0; s.fy = s.finit; s.gy = s.ginit;
   s.stmin = 0.0; s.stmax = stp + xtrapu * stp;
-  s.task = LS_FG;
+  s.task = bad ? LS_ERROR : LS_FG;
 }
 
 // Every later call: f, g are the objective and directional derivative at the trial step stp.  Two halves, so
@@ -471,7 +471,9 @@ struct Lbfgsb {
       T2_UNROLL
       for (int i = 0; i < N; ++i) { sp[i] = hs(0, i); yp[i] = hy(0, i); }
     }
-    for (int p = 0; p < col; ++p) {
+    T2_UNROLL
+    for (int p = 0; p < M; ++p) {
+      if (p >= col) continue;
       double sn[N], yn[N];
       const int pn = p + 1 < col ? p + 1 : p;
       T2_UNROLL
@@ -510,7 +512,8 @@ struct Lbfgsb {
     const double epsmch = 2.220446049250313e-16;
     T2_UNROLL
     for (int i = 0; i < N; ++i) xcp[i] = x[i];
-    if (sbgnrm <= 0.0) return;
+    // (no early exits in here either -- see begin_pass(): a lane with nothing to do computes along and keeps nothing)
+    const bool live = sbgnrm > 0.0;
     double d[N], tbk[N], zfix[N];
     bool hasbk[N];
     int nbreak = 0;
@@ -519,12 +522,10 @@ struct Lbfgsb {
     for (int i = 0; i < N; ++i) {
       const double neggi = -g[i];
       const double tl = x[i] - lb[i], tu = ub[i] - x[i];
-      if (iwhere[i] != 3) {
+      {
         const bool xlower = tl <= 0.0, xupper = tu <= 0.0;
-        iwhere[i] = 0;
-        if (xlower) { if (neggi <= 0.0) iwhere[i] = 1; }
-        else if (xupper) { if (neggi >= 0.0) iwhere[i] = 2; }
-        else if (t2_abs(neggi) <= 0.0) iwhere[i] = -3;
+        const int iw = xlower ? (neggi <= 0.0 ? 1 : 0) : (xupper ? (neggi >= 0.0 ? 2 : 0) : (t2_abs(neggi) <= 0.0 ? -3 : 0));
+        iwhere[i] = (live && iwhere[i] != 3) ? iw : iwhere[i];
       }
       d[i] = 0.0; tbk[i] = 0.0; zfix[i] = 0.0; hasbk[i] = false;
       if (iwhere[i] == 0) {
@@ -537,7 +538,7 @@ struct Lbfgsb {
         }
       }
     }
-    if (nbreak == 0) return;  // every moving variable is box-bounded here, so d == 0
+    const bool start = live && nbreak > 0;  // nbreak == 0: every moving variable is box-bounded here, so d == 0
     const double f2_org = -theta * f1;
     auto dBd = [&](const double* dd) {
       double s = 0.0;
@@ -552,7 +553,12 @@ struct Lbfgsb {
     double tsum = 0.0, tj = 0.0;
     int nleft = nbreak;
     bool all_fixed = false;
-    while (nleft > 0) {
+    // at most N breakpoints: N copies of the segment step instead of a loop (a back-edge here costs scalar registers
+    // across the whole begin-iteration block); `go` turns false where the loop would have been left
+    bool go = start;
+    T2_UNROLL
+    for (int seg = 0; seg < N; ++seg) {
+      if (!(go && nleft > 0)) continue;
       // next breakpoint: one-hot flags rather than an index, so that no local array is ever
       // indexed by a run-time value (the compiler would move it to scratch memory)
       bool pick[N];
@@ -572,7 +578,7 @@ struct Lbfgsb {
       const double tj0 = tj;
       tj = tmin;
       const double dt = tj - tj0;
-      if (dtm < dt) break;
+      if (dtm < dt) { go = false; continue; }
       T2_BLK_T0(t_bp)
       T2_BLK_END((*this), 1, t_bp)
       tsum += dt;
@@ -587,7 +593,7 @@ struct Lbfgsb {
           if (dibp > 0.0) { zfix[i] = ub[i] - x[i]; xcp[i] = ub[i]; iwhere[i] = 2; }
           else { zfix[i] = lb[i] - x[i]; xcp[i] = lb[i]; iwhere[i] = 1; }
         }
-      if (nleft == 0 && nbreak == N) { all_fixed = true; break; }
+      if (nleft == 0 && nbreak == N) { all_fixed = true; go = false; continue; }
       // derivatives of the quadratic model along the remaining direction, z = xcp - x so far
       double z[N];
       T2_UNROLL
@@ -604,11 +610,11 @@ struct Lbfgsb {
       if (nleft > 0) dtm = t2_fdiv(-f1, f2);
       else { f1 = 0.0; f2 = 0.0; dtm = 0.0; }  // all remaining variables are box-bounded
     }
-    if (all_fixed) return;
+    const bool commit = start && !all_fixed;
     dtm = t2_max(dtm, 0.0);
     tsum += dtm;
     T2_UNROLL
-    for (int i = 0; i < N; ++i) xcp[i] = fma(tsum, d[i], xcp[i]);
+    for (int i = 0; i < N; ++i) xcp[i] = commit ? fma(tsum, d[i], xcp[i]) : xcp[i];
   }
 
   // Direct primal subspace minimisation over the variables free at the Cauchy point, followed by
@@ -637,14 +643,14 @@ struct Lbfgsb {
     double rr[3] = {r[0], r[1], N == 3 ? r[N - 1] : 0.0};
     if (N == 2) rr[2] = 0.0;
     const double d0 = A[0][0];
-    if (!(d0 > 0.0)) return false;
     const double l10 = t2_fdiv(A[1][0], d0), l20 = t2_fdiv(A[2][0], d0);
     const double d1 = fma(-l10, A[1][0], A[1][1]);
-    if (!(d1 > 0.0)) return false;
     const double a21 = fma(-l20, A[1][0], A[2][1]);
     const double l21 = t2_fdiv(a21, d1);
     const double d2 = fma(-l21, a21, fma(-l20, A[2][0], A[2][2]));
-    if (!(d2 > 0.0)) return false;
+    // (no early exit on a non-positive pivot: the step is computed anyway -- NaN or nonsense then, thrown away by the
+    // caller, which begins the iteration again -- so that this is one straight block)
+    const bool pos_def = d0 > 0.0 && d1 > 0.0 && d2 > 0.0;
     const double y0 = rr[0], y1 = fma(-l10, y0, rr[1]), y2 = fma(-l21, y1, fma(-l20, y0, rr[2]));
     const double u2 = t2_fdiv(y2, d2), u1 = fma(-l21, u2, t2_fdiv(y1, d1));
     const double u0 = fma(-l20, u2, fma(-l10, u1, t2_fdiv(y0, d0)));
@@ -662,13 +668,10 @@ struct Lbfgsb {
         if (z[i] == lb[i] || z[i] == ub[i]) projected = true;
       }
     }
-    if (!projected) return true;
-    T2_BLK_T0(t_pj)
-    T2_BLK_END((*this), 2, t_pj)
     double ddp = 0.0;
     T2_UNROLL
     for (int i = 0; i < N; ++i) ddp = fma(z[i] - x[i], g[i], ddp);
-    if (ddp > 0.0) {  // not a descent direction: backtrack along du from the Cauchy point instead
+    if (projected && ddp > 0.0) {  // not a descent direction: backtrack along du from the Cauchy point instead
       T2_UNROLL
       for (int i = 0; i < N; ++i) z[i] = xp[i];
       double alpha = 1.0, temp1 = 1.0;
@@ -707,7 +710,7 @@ struct Lbfgsb {
       for (int i = 0; i < N; ++i)
         if (fr[i]) z[i] = fma(alpha, du[i], z[i]);
     }
-    return true;
+    return pos_def;
   }
 
   // Start a fit: x = x0 clipped into the box (scipy), empty memory.  Next: eval(), then advance().
@@ -836,13 +839,14 @@ struct Lbfgsb {
   // scalar-register spills alone; the persistent kernel simply calls again in its next round.
   T2_HD int begin_pass(const ObjCtx& c, int next) {
     const LaneParams& P = *c.P;
+    bool ended = false;
     if (next == GO_FAIL) {
       // line search could not be completed: back to the previous iterate.  With an empty memory
       // that is scipy's ABNORMAL termination (success False); otherwise drop the memory and redo.
       T2_UNROLL
       for (int i = 0; i < N; ++i) { x[i] = t[i]; g[i] = r[i]; }
       f = fold;
-      if (col == 0) return GO_DONE;
+      ended = col == 0;  // (the rest of the pass still runs for this lane, on values nobody reads afterwards)
       col = 0; theta = 1.0; wn_stale = false;
       T2_COUNT_RESET();
     }
@@ -881,7 +885,6 @@ struct Lbfgsb {
       wn_stale = false;
       col = 0; theta = 1.0;
       T2_COUNT_RESET();
-      return GO_BEGIN;
     }
     T2_BLK_T0(t_l)
     // line search along d = z - x (lnsrlb)
@@ -912,9 +915,10 @@ struct Lbfgsb {
     dcsrch_start(f, gd, stp, 1e-3, 0.0, stpmx, ls);  // ERROR also covers gd >= 0: not a descent direction
     ifun = 1;
     T2_BLK_END(c, 6, t_l)
-    if (ls.task != LS_FG || ifun - 1 >= P.maxls) return GO_FAIL;
-    set_trial();
-    return GO_TRIAL;
+    // what this pass amounts to, by value selects (no early exits above: the block is one straight line)
+    const int out = ended ? GO_DONE : (restart ? GO_BEGIN : ((ls.task != LS_FG || ifun - 1 >= P.maxls) ? GO_FAIL : GO_TRIAL));
+    if (out == GO_TRIAL) set_trial();
+    return out;
   }
 
   // everything between two evaluations: true when the fit has ended, false when `x` holds the next point to evaluate
