@@ -891,21 +891,18 @@ struct Lbfgsb {
     T2_UNROLL
     for (int i = 0; i < N; ++i) { d[i] = z[i] - x[i]; t[i] = x[i]; r[i] = g[i]; }
     stpmx = 1e10;
-    if (nit == 0) {
-      stpmx = 1.0;
-    } else {
-      T2_UNROLL
-      for (int i = 0; i < N; ++i) {
-        const double a1 = d[i];
-        if (a1 != 0.0) {  // lower bound limits a decreasing variable, upper bound an increasing one
-          const double a2 = (a1 < 0.0 ? lb[i] : ub[i]) - x[i];
-          const bool at_bound = a1 < 0.0 ? a2 >= 0.0 : a2 <= 0.0;
-          const bool limits = a1 < 0.0 ? a1 * stpmx < a2 : a1 * stpmx > a2;
-          if (at_bound) stpmx = 0.0;
-          else if (limits) stpmx = t2_fdiv(a2, a1);
-        }
-      }
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) {  // (selects, no branches; the quotient of a skipped variable is computed and dropped)
+      const double a1 = d[i];
+      // lower bound limits a decreasing variable, upper bound an increasing one
+      const double a2 = (a1 < 0.0 ? lb[i] : ub[i]) - x[i];
+      const bool at_bound = a1 < 0.0 ? a2 >= 0.0 : a2 <= 0.0;
+      const bool limits = a1 < 0.0 ? a1 * stpmx < a2 : a1 * stpmx > a2;
+      const double q = t2_fdiv(a2, a1);
+      const double cand = at_bound ? 0.0 : (limits ? q : stpmx);
+      stpmx = a1 != 0.0 ? cand : stpmx;
     }
+    stpmx = nit == 0 ? 1.0 : stpmx;
     stp = 1.0;  // every variable is boxed, so the first step is not rescaled by 1/|d|
     fold = f;
     gd = 0.0;
@@ -943,7 +940,7 @@ struct Lbfgsb {
 template <int MODEL>
 T2_HD void lbfgsb_solve(const ObjCtx& c, const double* lb, const double* ub, LaneResult& out) {
   Lbfgsb<MODEL> s;
-  double hist[2 * Lbfgsb<MODEL>::M * Lbfgsb<MODEL>::N];
+  double hist[2 * Lbfgsb<MODEL>::M * Lbfgsb<MODEL>::N] = {};
   s.init(c.P->x0, lb, ub, hist, 1);
   do {
     s.eval(c);

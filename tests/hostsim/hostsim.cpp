@@ -121,7 +121,7 @@ extern "C" int hostsim_eval_points(const t2fit_config* cfg, const float* row, do
   if (!lane_bounds(P, y0_raw, lb, ub) || !finite) return -10;
   *n_out = 0;
   auto run = [&](auto& s) {
-    double hist[60];
+    double hist[60] = {};
     s.init(P.x0, lb, ub, hist, 1);
     do {
       s.eval(c);
