@@ -299,11 +299,12 @@ template <int MODEL, int NTE = 0> struct LbfgsbLane {
                               double* hist) { s.init(x0, lb, ub, hist, kBlock); }
   __device__ static void result(const Solver& s, const ObjCtx&, LaneResult& r) { s.result(r); }
 };
-template <typename T, int NPAR> struct LmLaneAdaptor {
-  using Solver = LmLane<T, NPAR>;
+template <typename T, int NPAR, int NTE = 0> struct LmLaneAdaptor {
+  using Solver = LmLane<T, NPAR, NTE>;
   static constexpr int NP = NPAR;
-  static constexpr int kNte = 0;
+  static constexpr int kNte = NTE;
   static constexpr int kHistDoubles = 0;
+  // float32: four waves per SIMD (128 registers); float64: what the 229 registers of the lane allow (two, LDS permitting)
   static constexpr int kWavesPerSimd = sizeof(T) == 4 ? 4 : 1;
   static constexpr int kRefillMin = 24;  // measured (f32, 3 parameters, MI355X): 8 -> 1.62 ms, 16 -> 1.42 ms, 24 -> 1.35 ms, 32 -> 1.35 ms
   static constexpr bool kSplit = false;
@@ -839,12 +840,25 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
       else if (cfg->model == T2FIT_MODEL_GAUSSIAN_RICIAN) T2_LBFGSB(T2FIT_MODEL_GAUSSIAN_RICIAN);
       else T2_LBFGSB(T2FIT_MODEL_RICIAN);
 #undef T2_LBFGSB
-    } else if (cfg->precision == T2FIT_PREC_F32) {
-      if (cfg->model == T2FIT_MODEL_GAUSSIAN) T2_PERSIST(LmLaneAdaptor<float, 2>);
-      else T2_PERSIST(LmLaneAdaptor<float, 3>);
     } else {
-      if (cfg->model == T2FIT_MODEL_GAUSSIAN) T2_PERSIST(LmLaneAdaptor<double, 2>);
-      else T2_PERSIST(LmLaneAdaptor<double, 3>);
+      // converged LM lane; on large volumes with a common echo-train length the echo-count specialisation
+      const bool large = !dm.trace && n_vox > kSmallVolume && g_nte_special;
+      const bool f32 = cfg->precision == T2FIT_PREC_F32, two = cfg->model == T2FIT_MODEL_GAUSSIAN;
+#define T2_LM(T, NPAR)                                                                                                 \
+  do {                                                                                                                 \
+    if (large && cfg->n_te == 8) pe = launch_persistent<LmLaneAdaptor<T, NPAR, 8>, true>(pgrid, lds, st, P, echoes, layout, mask, n_vox, dm, counter); \
+    else if (large && cfg->n_te == 6) pe = launch_persistent<LmLaneAdaptor<T, NPAR, 6>, true>(pgrid, lds, st, P, echoes, layout, mask, n_vox, dm, counter); \
+    else if (large && cfg->n_te == 3) pe = launch_persistent<LmLaneAdaptor<T, NPAR, 3>, true>(pgrid, lds, st, P, echoes, layout, mask, n_vox, dm, counter); \
+    else T2_PERSIST(LmLaneAdaptor<T, NPAR>);                                                                           \
+  } while (0)
+      // (float32 stays on the generic lane: the specialised evaluation keeps eight echoes in flight, which does not fit
+      // the 128 registers of four waves per SIMD -- 204 B/lane of scratch, 2.0 ms -- and loses at three waves: 1.27 vs
+      // 1.20 ms; float64: 2.73 vs 2.96 ms)
+      if (f32 && two) T2_PERSIST(LmLaneAdaptor<float, 2>);
+      else if (f32) T2_PERSIST(LmLaneAdaptor<float, 3>);
+      else if (two) T2_LM(double, 2);
+      else T2_LM(double, 3);
+#undef T2_LM
     }
 #undef T2_PERSIST
     if (pe != hipSuccess) return fail(T2FIT_E_HIP, std::string("persistent fit launch: ") + hipGetErrorString(pe));

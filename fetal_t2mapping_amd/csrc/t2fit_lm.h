@@ -33,10 +33,10 @@ template <typename T> struct LmEval {
 // removes the flat, badly scaled sigma direction the (k, T2, sigma) form has when sigma << k E
 // (d m / d sigma = sigma / m -> 0) and halves the number of iterations.  The model is even in k and
 // sigma, so squaring loses nothing; the box maps monotonically.
-template <typename T, int NP>
+template <typename T, int NP, int NTE = 0>
 T2_HD void lm_eval(const ObjCtx& c, const T* q, LmEval<T>& e) {
   const LaneParams& P = *c.P;
-  const int n = P.n_te;
+  const int n = NTE > 0 ? NTE : P.n_te;  // NTE > 0: echo count known at compile time (one straight block)
   const T k = q[0], R = q[1], s = (NP == 3) ? q[2] : T(0);
   T f = 0, akk = 0, akr = 0, aks = 0, arr = 0, ars = 0, ass = 0, gk = 0, gr = 0, gs = 0;
   auto echo = [&](int i) {
@@ -146,7 +146,7 @@ T2_HD bool loglinear_seed(const ObjCtx& c, T& k, T& R) {
 
 // Resumable form (same protocol as Lbfgsb): init() seeds the fit, eval() evaluates residuals and
 // Jacobian at the pending point, advance() accepts or rejects it and proposes the next one.
-template <typename T, int NP>
+template <typename T, int NP, int NTE = 0>
 struct LmLane {
   T lo[3], hi[3];        // box in (k | k^2, R, sigma^2)
   T q[3], qn[3], d[3];   // accepted point, pending point, step that led to it
@@ -205,7 +205,7 @@ struct LmLane {
     first = true;
   }
 
-  T2_HD void eval(const ObjCtx& c) { lm_eval<T, NP>(c, qn, en); }
+  T2_HD void eval(const ObjCtx& c) { lm_eval<T, NP, NTE>(c, qn, en); }
 
   // the current run has ended with `status`; returns false if a second run was started instead
   T2_HD bool finish_run(const LaneParams& P) {
