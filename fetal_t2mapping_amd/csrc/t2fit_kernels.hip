@@ -14,6 +14,10 @@
 // res) = 49 B at 8 TE.  The fit itself is ALU work (exp/sqrt/div/fma, fp64 or fp32); no MFMA:
 // nothing here is a contraction.
 #include <hip/hip_runtime.h>
+#if defined(T2_WG_SHAPE_DIAG)
+#include <array>
+#include <map>
+#endif
 
 #include <algorithm>
 #include <cstdio>
@@ -34,6 +38,12 @@ constexpr int kBlock = 256;
 constexpr int kLdsStride = kBlock + 1;
 bool g_use_persistent = true;  // LM: false selects the one-voxel-per-lane kernel (T2FIT_ONE_SHOT=1)
 int g_refill_min = 0;           // > 0 overrides the per-solver refill batch (T2FIT_REFILL_MIN)
+#ifndef T2_WAVE_HINT
+#define T2_WAVE_HINT 2
+#endif
+constexpr int kWaveHint = T2_WAVE_HINT;  // occupancy the register allocator / scheduler is told for the one-wave workgroups
+int g_waves_per_cu = 0;         // T2FIT_WAVES_PER_CU: cap of the above (A/B runs)
+int g_wave_wg = 1;         // one-wave workgroups for the large-volume L-BFGS-B kernels (T2FIT_WAVE_WG=0: 256-lane workgroups)
 int g_persistent_blocks = 2048;  // grid of the persistent kernel (T2FIT_PERSISTENT_BLOCKS overrides)
 int g_reserve_cus = 0;           // T2FIT_RESERVE_CUS: CUs the one-workgroup-per-CU L-BFGS-B kernel leaves free
 bool g_nte_special = true;       // T2FIT_NTE_SPECIAL=0: always the generic-echo-count lane (A/B switch)
@@ -284,7 +294,12 @@ constexpr int kChunkSmall = 64;   // small volumes (phantoms): more, smaller chu
 constexpr int64_t kSmallVolume = 1 << 20;
 constexpr int kQueueCap = 64 + kChunkLarge;
 constexpr int kDiagBlocks = 11, kDiagWords = 3 * kDiagBlocks;  // -DT2_PHASE_STAMPS: (cycles, lanes, entries) per block
-constexpr int kCounterWords = 16 + kDiagWords;                  // chunk counter + diagnostic totals
+#if defined(T2_WG_SHAPE_DIAG)
+constexpr int kPlaceWords = 4096;  // diagnostic build: HW_ID / XCC_ID of every wave of the persistent kernel
+#else
+constexpr int kPlaceWords = 0;
+#endif
+constexpr int kCounterWords = 16 + kDiagWords + kPlaceWords;    // chunk counter + diagnostic totals
 
 // what the persistent kernel needs to know about a resumable lane solver
 template <int MODEL, int NTE = 0> struct LbfgsbLane {
@@ -293,39 +308,53 @@ template <int MODEL, int NTE = 0> struct LbfgsbLane {
   static constexpr int kNte = NTE;  // > 0: the echo count is a compile-time constant (the refill loops flatten too)
   static constexpr int kHistDoubles = 2 * Solver::M * Solver::N;  // correction pairs, per lane, in LDS
   static constexpr int kWavesPerSimd = 1;
+  // one-wave workgroups, two waves on a SIMD: the Rician lane (i0e) needs more than the 256 registers that allows
+  static constexpr bool kWaveWgOk = MODEL != T2FIT_MODEL_RICIAN;
   static constexpr int kRefillMin = 8;   // measured on MI355X: 1 -> 28.1 ms, 8 -> 26.8 ms, 16 -> 27.6 ms
   static constexpr bool kSplit = true;   // advance() = digest() + begin(): the kernel may batch begin() (T2FIT_PARK_MIN)
   __device__ static void init(Solver& s, const ObjCtx&, const double* x0, const double* lb, const double* ub,
-                              double* hist) { s.init(x0, lb, ub, hist, kBlock); }
+                              double* hist, int hstride) { s.init(x0, lb, ub, hist, hstride); }
   __device__ static void result(const Solver& s, const ObjCtx&, LaneResult& r) { s.result(r); }
+  template <int J> __device__ static void take_sample(Solver& s, float y) {
+    if constexpr (NTE > 0 && J < NTE) s.ys[J] = y;
+  }
 };
 template <typename T, int NPAR, int NTE = 0> struct LmLaneAdaptor {
   using Solver = LmLane<T, NPAR, NTE>;
   static constexpr int NP = NPAR;
   static constexpr int kNte = NTE;
   static constexpr int kHistDoubles = 0;
+  static constexpr bool kWaveWgOk = false;
   // float32: four waves per SIMD (128 registers); float64: what the 229 registers of the lane allow (two, LDS permitting)
   static constexpr int kWavesPerSimd = sizeof(T) == 4 ? 4 : 1;
   static constexpr int kRefillMin = 24;  // measured (f32, 3 parameters, MI355X): 8 -> 1.62 ms, 16 -> 1.42 ms, 24 -> 1.35 ms, 32 -> 1.35 ms
   static constexpr bool kSplit = false;
   __device__ static void init(Solver& s, const ObjCtx& c, const double* x0, const double* lb, const double* ub,
-                              double*) { s.init(c, x0, lb, ub); }
+                              double*, int) { s.init(c, x0, lb, ub); }
   __device__ static void result(const Solver& s, const ObjCtx& c, LaneResult& r) { s.result(c, r); }
+  template <int J> __device__ static void take_sample(Solver&, float) {}
 };
 
-template <class A, int kChunk, bool kTrace, bool kExtras>
+template <class A, int kChunk, bool kTrace, bool kExtras, int kWg = kBlock, bool kRegs = false>
 __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float* __restrict__ echoes, int layout,
                                                const uint8_t* __restrict__ mask, int64_t n_vox, const DevMaps& m,
                                                unsigned long long* next_chunk, int refill_min, int park_min) {
   extern __shared__ float lds[];
   constexpr int NP = A::NP;
+  // kWg == 64: one wave per workgroup (see launch_persistent: more waves per CU than four), queue in a register
+  constexpr bool kWaveWg = kRegs;
+  static_assert(kRegs ? (kChunk == 64 && A::kNte > 0 && A::kNte <= 8) : kWg == kBlock,
+                "workgroup of 256 lanes, or waves taking 64-voxel chunks with the samples in registers");
+  constexpr int kStride = kWaveWg ? 64 : kLdsStride;  // sample columns: the +1 pad is for the 256-wide transposes only
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* col = lds + threadIdx.x;
-  // LDS: [n_te][257] float sample columns | [kHistDoubles][256] double solver history | 4 queues
-  double* hist = reinterpret_cast<double*>(lds + ((P.n_te * kLdsStride + 1) & ~1)) + threadIdx.x;
-  uint32_t* queue = reinterpret_cast<uint32_t*>(hist - threadIdx.x + A::kHistDoubles * kBlock) + wave * kQueueCap;
+  // LDS, kWg == 256: [n_te][257] float sample columns | [kHistDoubles][256] double solver history | 4 queues
+  //      kWg == 64:  [kHistDoubles][64] double solver history, nothing else (samples and queue are in registers)
+  double* hist = reinterpret_cast<double*>(lds + (kWaveWg ? 0 : ((P.n_te * kStride + 1) & ~1))) + threadIdx.x;
+  uint32_t* queue = reinterpret_cast<uint32_t*>(hist - threadIdx.x + A::kHistDoubles * kWg) + wave * kQueueCap;
+  uint32_t qv = 0;  // kWaveWg: lane r holds the r-th waiting voxel of the chunk last taken
   const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  const EchoView y{col, kLdsStride};
+  const EchoView y{col, kStride};
   int q_head = 0, q_count = 0;
   bool chunks_left = true;
   bool busy = false, done = false;
@@ -345,8 +374,35 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
   c.diag = diag;
   const unsigned long long st_all = __builtin_amdgcn_s_memtime();
 #endif
+#if defined(T2_WG_SHAPE_DIAG)  // where did the dispatcher put this wave?
+  {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned w = blockIdx.x * (kWg / 64) + wave;
+    if (lane == 0 && w < (unsigned)kPlaceWords) next_chunk[16 + kDiagWords + w] = 0x100000000ull | ((unsigned long long)(xcc & 0xf) << 20) | (hw & 0xfffff);
+  }
+#endif
   bool parked = false;  // split solvers: digest() done, begin() pending (see park_min below)
   int pend = 0;
+  // kWaveWg: the chunk queue is read two steps ahead, so that taking a chunk never waits for memory -- chunk A has
+  // its base and its mask bytes (loaded when the chunk before it was taken), chunk B its counter value (lane 0)
+  constexpr int kTake = 4;  // one counter increment hands a wave kTake 64-voxel chunks in a row (fewer same-address atomics)
+  int64_t base_a = 0;
+  int sub_a = 0;
+  uint32_t idx_b = 0;
+  uint8_t mask_a = 0;
+  auto load_mask = [&](int64_t base) -> uint8_t {
+    const int64_t vv = base + lane;
+    return vv < n_vox ? (mask ? mask[vv] : (uint8_t)1) : (uint8_t)0;
+  };
+  if constexpr (kWaveWg) {
+    uint32_t c0 = 0;
+    if (lane == 0) c0 = (uint32_t)atomicAdd(next_chunk, 1ull);
+    base_a = (int64_t)__shfl(c0, 0, 64) * (64 * kTake);
+    mask_a = load_mask(base_a);
+    if (lane == 0) idx_b = (uint32_t)atomicAdd(next_chunk, 1ull);
+  }
   for (;;) {
     // Refill in batches: the refill path (sample loads, seed / set-up) runs with only the idle lanes
     // active, so it is entered when at least refill_min lanes are idle (or nothing is running).
@@ -361,6 +417,54 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
         store_fit<kExtras>(m, v, r);
         done = false;
       }
+      bool fresh = false;
+      if constexpr (kWaveWg) {
+        // The queue is one register: a chunk's active voxels are compacted into lanes 0.. (ds_permute: lane j sends its
+        // voxel to the lane of its rank among the active ones) and idle lane number r reads entry q_head + r back
+        // (ds_bpermute).  Serve from what is left of the last chunk, then take chunks until every idle lane has a voxel.
+        unsigned long long want = need;
+        for (;;) {
+          if (q_count == 0) {
+            if (!chunks_left) break;
+            const int64_t base = base_a;
+            if (base >= n_vox) { chunks_left = false; break; }
+            const int64_t vv = base + lane;
+            const bool act = mask_a != 0;
+            // step the read-ahead: B's counter value has been back for a while; its mask bytes and the next counter
+            // value are needed when the next chunk is taken, many rounds from now
+            if (++sub_a < kTake) {
+              base_a += 64;
+              mask_a = load_mask(base_a);
+            } else {
+              sub_a = 0;
+              base_a = (int64_t)__shfl(idx_b, 0, 64) * (64 * kTake);
+              mask_a = load_mask(base_a);
+              if (lane == 0) idx_b = (uint32_t)atomicAdd(next_chunk, 1ull);
+            }
+            const unsigned long long b = __ballot(act);
+            q_count = __popcll(b);
+            q_head = 0;
+            // a full permutation: active lanes to the front in order, the others behind them
+            const int dst = act ? __popcll(b & lt_mask) : q_count + __popcll(~b & lt_mask);
+            qv = (uint32_t)__builtin_amdgcn_ds_permute(dst << 2, (int)(uint32_t)vv);
+            if (vv < n_vox && !act) store_masked<kExtras>(m, vv);
+            if (q_count == 0) continue;
+          }
+          const int rank = __popcll(want & lt_mask);
+          const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute(((q_head + rank) & 63) << 2, (int)qv);
+          if (!busy && rank < q_count) {
+            v = (int64_t)got;
+            busy = true;
+            fresh = true;
+          }
+          const int n_want = __popcll(want);
+          const int taken = n_want < q_count ? n_want : q_count;
+          q_head += taken;
+          q_count -= taken;
+          want = __ballot(!busy);
+          if (want == 0ull) break;
+        }
+      } else {
       const int n_need = __popcll(need);
       while (q_count < n_need && chunks_left) {
         unsigned long long cidx = 0;
@@ -394,7 +498,6 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
           if (vv < n_vox && !act[q]) store_masked<kExtras>(m, vv);
         }
       }
-      bool fresh = false;
       if (!busy) {
         const int rank = __popcll(need & lt_mask);
         if (rank < q_count) {
@@ -406,12 +509,14 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
       const int taken = n_need < q_count ? n_need : q_count;
       q_head += taken;
       q_count -= taken;
+      }
       if (fresh) {
         // this lane's samples: up to 8 loads in flight, checked in registers, parked in its LDS
         // column (already divided by the row maximum when cfg.norm, run_t2mapping.py:237-238)
         bool finite = true;
         float ymax = 0.0f, y0 = 0.0f;
         const int n_te = A::kNte > 0 ? A::kNte : P.n_te;
+        float first8[8] = {};  // echo-count specialisations: the samples stay in registers (A::take_sample)
         for (int i0 = 0; i0 < n_te; i0 += 8) {
           float tmp[8];
 #pragma unroll
@@ -423,19 +528,33 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
           for (int j = 0; j < 8; ++j)
             if (i0 + j < n_te) {
               const float sv = tmp[j];
-              col[(i0 + j) * kLdsStride] = sv;
+              if constexpr (!kWaveWg) col[(i0 + j) * kStride] = sv;
+              if (i0 == 0) first8[j] = sv;
               finite = finite && t2_finite(sv);
               if (i0 + j == 0) { y0 = sv; ymax = sv; }
               ymax = sv > ymax ? sv : ymax;
             }
         }
         if (P.norm) {
-          for (int i = 0; i < n_te; ++i) {
-            const float sv = col[i * kLdsStride] / ymax;
-            col[i * kLdsStride] = sv;
-            finite = finite && t2_finite(sv);
+          if constexpr (A::kNte > 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (j < n_te) {
+                const float sv = first8[j] / ymax;
+                first8[j] = sv;
+                if constexpr (!kWaveWg) col[j * kStride] = sv;
+                finite = finite && t2_finite(sv);
+              }
+          } else {
+            for (int i = 0; i < n_te; ++i) {
+              const float sv = col[i * kStride] / ymax;
+              col[i * kStride] = sv;
+              finite = finite && t2_finite(sv);
+            }
           }
         }
+        if constexpr (A::kNte > 0)
+          static_for<0, 8>([&](auto JC) { A::template take_sample<decltype(JC)::value>(s, first8[decltype(JC)::value]); });
         double lb[3], ub[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) { lb[j] = box_lb[j]; ub[j] = box_ub[j]; }
@@ -461,7 +580,7 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
             c.trace_n = m.trace_len + v;
             *c.trace_n = 0;
           }
-          A::init(s, c, box_x0, lb, ub, hist);
+          A::init(s, c, box_x0, lb, ub, hist, kWg);
 #if defined(T2_PHASE_STAMPS)
           if constexpr (A::kSplit) s.diag = diag;
 #endif
@@ -520,13 +639,14 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
 // The kernel proper.  kWavesPerSimd is the occupancy the register allocator is asked to keep: 1 for the
 // float64 solvers (the L-BFGS-B lane alone holds ~340 registers), 4 for the float32 LM lane, which sits a few
 // registers above the 128-register line of four waves per SIMD without the hint.
-template <class A, int kChunk, bool kTrace = false, int kWavesPerSimd = 1, bool kExtras = true>
-__global__ __launch_bounds__(kBlock, kWavesPerSimd) void fit_persistent_kernel(const LaneParams P,
-                                                                       const float* __restrict__ echoes, int layout,
-                                                                       const uint8_t* __restrict__ mask, int64_t n_vox,
-                                                                       DevMaps m, unsigned long long* next_chunk, int refill_min,
-                                                                       int park_min) {
-  persistent_fit<A, kChunk, kTrace, kExtras>(P, echoes, layout, mask, n_vox, m, next_chunk, refill_min, park_min);
+template <class A, int kChunk, bool kTrace = false, int kWavesPerSimd = 1, bool kExtras = true, int kWg = kBlock,
+          bool kRegs = false>
+__global__ __launch_bounds__(kWg, kWavesPerSimd) void fit_persistent_kernel(const LaneParams P,
+                                                                    const float* __restrict__ echoes, int layout,
+                                                                    const uint8_t* __restrict__ mask, int64_t n_vox,
+                                                                    DevMaps m, unsigned long long* next_chunk, int refill_min,
+                                                                    int park_min) {
+  persistent_fit<A, kChunk, kTrace, kExtras, kWg, kRegs>(P, echoes, layout, mask, n_vox, m, next_chunk, refill_min, park_min);
 }
 
 // Residual map (utils/t2map_utils.py:62-89) and optional R^2 from float32 maps already on the device.
@@ -733,6 +853,42 @@ hipError_t launch_persistent(unsigned grid, size_t lds_samples, hipStream_t st, 
                              unsigned long long* counter) {
   constexpr int W = A::kWavesPerSimd;
   const bool extras = dm.r2 || dm.se || dm.fun || dm.nit || dm.status || dm.xd || dm.fund;
+#if !defined(T2_PHASE_STAMPS)
+  if constexpr (kLargeOnly && A::kHistDoubles > 0 && A::kWaveWgOk) {
+    // One-wave workgroups.  The lane's correction pairs (480 B with three parameters, 320 B with two) cap a CU's
+    // 160 KiB of LDS at 341 lanes: four waves as one 256-lane workgroup, but FIVE as one-wave workgroups (eight with
+    // two parameters) -- the lane fits 256 registers, so one SIMD (all four) of each CU then interleaves two waves.
+    // Nothing but the pairs is in LDS: the samples are in registers (echo-count specialisation), the voxel queue too.
+    if (g_wave_wg) {
+      // (T2FIT_WAVE_WG=2 / 3: the same register-queue code in workgroups of 256 / 128 lanes -- diagnostic builds only)
+      auto k64 = extras ? fit_persistent_kernel<A, kChunkSmall, false, kWaveHint, true, 64, true>
+                        : fit_persistent_kernel<A, kChunkSmall, false, kWaveHint, false, 64, true>;
+      unsigned wg = 64;
+#if defined(T2_WG_SHAPE_DIAG)
+      if (g_wave_wg == 2) { k64 = fit_persistent_kernel<A, kChunkSmall, false, 1, false, 256, true>; wg = 256; }
+      if (g_wave_wg == 3) { k64 = fit_persistent_kernel<A, kChunkSmall, false, 1, false, 128, true>; wg = 128; }
+#endif
+      size_t lds64 = (size_t)A::kHistDoubles * wg * sizeof(double);
+      // (LDS is handed out in 1280-byte pieces, 128 to a CU: measured with tools/diag/wave_placement_probe.hip, five
+      // workgroups of 32000 bytes are resident together, of 32768 four)
+      unsigned per_cu = (unsigned)std::min<size_t>(512 / wg, 128 / ((lds64 + 1279) / 1280));
+      if (g_waves_per_cu > 0 && (unsigned)g_waves_per_cu < per_cu) {  // A/B switch: pad the allocation so that no more fit
+        per_cu = (unsigned)g_waves_per_cu;
+        lds64 = (size_t)(128 / per_cu) * 1280;
+      }
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k64), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds64);
+      if (e != hipSuccess) return e;
+      int dev = 0, cus = 0;
+      if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+      if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+      grid = std::min<unsigned>(grid, (unsigned)cus);  // every wave that fits is resident; more would only start to leave
+      hipLaunchKernelGGL(k64, dim3(grid * per_cu), dim3(wg), lds64, st, P, echoes, layout, mask, n_vox, dm, counter,
+                         g_refill_min > 0 ? g_refill_min : A::kRefillMin, g_park_min);
+      return hipGetLastError();
+    }
+  }
+#endif
   auto kern = extras ? fit_persistent_kernel<A, kChunkLarge, false, W, true>
                      : fit_persistent_kernel<A, kChunkLarge, false, W, false>;
   if constexpr (!kLargeOnly) {
@@ -796,6 +952,8 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
     if (const char* e = std::getenv("T2FIT_RESERVE_CUS")) g_reserve_cus = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("T2FIT_NTE_SPECIAL")) g_nte_special = std::atoi(e) != 0;
     if (const char* e = std::getenv("T2FIT_PARK_MIN")) g_park_min = std::min(64, std::max(1, std::atoi(e)));
+    if (const char* e = std::getenv("T2FIT_WAVE_WG")) g_wave_wg = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("T2FIT_WAVES_PER_CU")) g_waves_per_cu = std::max(0, std::atoi(e));
     return true;
   }();
   (void)env_read;
@@ -896,6 +1054,29 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
               names[i], 100.0 * (double)d[0] / life, d[2] ? (double)d[1] / (double)d[2] : 0.0, d[2],
               d[2] ? (double)d[0] / (double)d[2] : 0.0);
     }
+  }
+#endif
+#if defined(T2_WG_SHAPE_DIAG)
+  if (counter && cfg->solver == T2FIT_SOLVER_LBFGSB && std::getenv("T2FIT_PLACEMENT")) {
+    std::vector<unsigned long long> h(kCounterWords);
+    T2_HIP(hipMemcpyAsync(h.data(), counter, h.size() * 8, hipMemcpyDeviceToHost, st));
+    T2_HIP(hipStreamSynchronize(st));
+    std::map<unsigned, std::array<int, 4>> cu;
+    for (int i = 0; i < kPlaceWords; ++i) {
+      const unsigned long long v = h[16 + kDiagWords + i];
+      if (!(v >> 32)) continue;
+      const unsigned hw = (unsigned)v & 0xfffff, xcc = ((unsigned)v >> 20) & 0xf;
+      cu[(xcc << 16) | ((hw >> 8) & 0xff)][(hw >> 4) & 3]++;
+    }
+    std::map<std::string, int> pat;
+    for (auto& kv : cu) {
+      std::array<int, 4> c = kv.second;
+      std::sort(c.begin(), c.end());
+      char b[64];
+      snprintf(b, sizeof b, "%d,%d,%d,%d", c[3], c[2], c[1], c[0]);
+      pat[b]++;
+    }
+    for (auto& kv : pat) fprintf(stderr, "[t2fit placement] %4d CUs with waves per SIMD %s\n", kv.second, kv.first.c_str());
   }
 #endif
   if (counter) T2_HIP(hipFreeAsync(counter, st));

@@ -318,6 +318,13 @@ struct Lbfgsb {
   uint8_t status;
   bool first;
   bool wn_stale;  // the library's WN1 matrix would be out of date (see begin())
+  // echo-count specialisations keep the voxel's samples in registers (eval() indexes them with constants only), so
+  // the kernel needs no LDS for them: what decides how many waves a CU holds is the correction-pair ring alone
+  float ys[NTE > 0 ? NTE : 1];
+  T2_HD float smp(const ObjCtx& c, int i) const {
+    if constexpr (NTE > 0) return ys[i];
+    else return c.sample(i);
+  }
 #if defined(T2_PHASE_STAMPS)
   unsigned long long* diag = nullptr;  // diagnostic build: the wave's block counters, for the const helpers
 #endif
@@ -372,7 +379,7 @@ struct Lbfgsb {
       const double k = x[0], t2 = x[1], kp = x1[0], t2p = x1[1];
       const double rt2 = t2_rcp_for_div(t2), rt2p = t2_rcp_for_div(t2p);  // one reciprocal per T2, shared by every echo
       auto body = [&](int i, auto add) {
-        const double y = (double)c.sample(i), te = P.te[i];
+        const double y = (double)smp(c, i), te = P.te[i];
         const double E = t2_exp_core(t2_div_by_rcp(-te, t2, rt2)), Ep = t2_exp_core(t2_div_by_rcp(-te, t2p, rt2p));
         const double r0 = y - k * E, r1 = y - kp * E, r2 = y - k * Ep;
         add(r0 * r0, r1 * r1, r2 * r2, 0.0);
@@ -390,7 +397,7 @@ struct Lbfgsb {
       const double sg2 = x[N - 1] * x[N - 1], sgp2 = x1[N - 1] * x1[N - 1];
       const double rt2 = t2_rcp_for_div(t2), rt2p = t2_rcp_for_div(t2p);
       auto body = [&](int i, auto add) {
-        const double y = (double)c.sample(i), te = P.te[i];
+        const double y = (double)smp(c, i), te = P.te[i];
         const double E = t2_exp_core(t2_div_by_rcp(-2.0 * te, t2, rt2)), Ep = t2_exp_core(t2_div_by_rcp(-2.0 * te, t2p, rt2p));
         const double r0 = y - t2_sqrt_core(k2 * E + sg2), r1 = y - t2_sqrt_core(kp2 * E + sg2);
         const double r2 = y - t2_sqrt_core(k2 * Ep + sg2), r3 = y - t2_sqrt_core(k2 * E + sgp2);
@@ -421,7 +428,7 @@ struct Lbfgsb {
         return (a - b) + dd;
       };
       auto body = [&](int i, auto add) {
-        const float yf = c.sample(i);
+        const float yf = smp(c, i);
         const double te = P.te[i];
         const double E = t2_exp_core(t2_div_by_rcp(-te, t2, rt2)), Ep = t2_exp_core(t2_div_by_rcp(-te, t2p, rt2p));
         add(term(k, E, sg2, rs2, ls2, yf), term(kp, E, sg2, rs2, ls2, yf), term(k, Ep, sg2, rs2, ls2, yf),

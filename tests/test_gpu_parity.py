@@ -855,6 +855,49 @@ def test_config2_and_config3_adult_brain_at_size(t2):
         del a, b, lo, hi
 
 
+@pytest.mark.parametrize("fit,n_te,prior,norm", [("gaussian_rician", 8, True, False), ("gaussian_rician", 6, False, False),
+                                                 ("gaussian_rician", 3, True, True), ("gaussian", 6, True, False),
+                                                 ("gaussian", 8, False, True), ("rician", 6, True, False)],
+                         ids=lambda v: str(v))
+def test_large_volume_kernels_equal_the_small_volume_kernel(t2, fit, n_te, prior, norm):
+    """Volumes above 2^20 voxels with 8 / 6 / 3 echoes run the echo-count specialised kernels (one-wave workgroups with
+    samples and voxel queue in registers for the 2- and 3-parameter Gaussian objectives: five / eight waves per CU),
+    everything else the generic 256-lane kernel.  Same voxels, cut into pieces small enough for the generic kernel:
+    the maps must agree bit for bit -- with a ragged voxel count (not a multiple of 64), without a mask, with the
+    normalised signal, under --no_prior."""
+    import torch
+
+    from fetal_t2mapping_amd import synth
+
+    dev = torch.device("cuda", 0)
+    shape = (40, 256, 256)
+    echoes, mask, te = synth.brain_volume_torch(shape, n_te, synth.SEED_BASE + 11, dev)
+    n = shape[0] * shape[1] * shape[2] - 37  # ragged: the last chunk of 64 is cut
+    echoes = echoes[:, :n].contiguous()
+    table = t2.fit_table(fit, True)
+    if norm:  # signals in (0, 1]: a table on that scale
+        table = dict(table)
+        three = len(table["initial_guess"]) == 3
+        table["initial_guess"] = [0.9, table["initial_guess"][1]] + ([0.05] if three else [])
+        table["param_bounds"] = [(0.1, 2.0), table["param_bounds"][1]] + ([(1e-3, 1.0)] if three else [])
+    for msk in (mask[:n].contiguous(), None):
+        if msk is None and fit == "rician":
+            continue  # (slow objective: the masked case covers it)
+        whole = t2.fit_volume(echoes.reshape(n_te, 1, 1, n), msk, te, fit, table, prior=prior, norm=norm, extras=True)
+        piece = 1 << 19
+        for lo in range(0, n, piece):
+            hi = min(n, lo + piece)
+            part = t2.fit_volume(echoes[:, lo:hi].contiguous().reshape(n_te, 1, 1, hi - lo),
+                                 None if msk is None else msk[lo:hi].contiguous(), te, fit, table, prior=prior, norm=norm,
+                                 extras=True)
+            for name in ("t2", "k", "sigma", "res", "nit", "status"):
+                assert _bitwise_equal(getattr(whole, name).reshape(-1)[lo:hi], getattr(part, name).reshape(-1)), (name, lo)
+        st = whole.status.reshape(-1)
+        fitted = st != 0 if msk is None else msk.bool()
+        assert float(((st[fitted] == 1) | (st[fitted] == 2)).float().mean()) > 0.99
+        del whole
+
+
 def test_config4_whole_uterus_slabs_equal_whole_volume(t2):
     """BASELINE.json config 4: 512 x 512 x 360 x 8 TE (94.4 M voxels, 3 GB of samples), the volume that is cut over
     eight GPUs.  One GPU holds it whole, so the partition can be checked at full size without the other seven: the fit
