@@ -396,8 +396,9 @@ def main():
                          "kernel_ms": round(k_ms, 4),
                          "bytes_per_voxel": bytes_per_voxel, "voxels_per_launch": n_vox,
                          "note": ("one streaming pass, HBM bound" if a.solver == "loglin" else
-                                  "the fit is float64 VALU-issue bound (about 4500 wave instructions per evaluation round "
-                                  "at one wave per SIMD), not HBM bound: see DESIGN.md section 6 and `alu`")},
+                                  "the fit is float64 VALU-issue bound (about 4500 wave instructions per evaluation round; "
+                                  "its LDS-resident correction pairs allow five waves per CU), not HBM bound: see DESIGN.md "
+                                  "section 6 and `alu`")},
         }
         alu = alu_view(key, k_ms) if n_vox == n_vol else None
         if alu is not None:

@@ -38,6 +38,9 @@ constexpr int kBlock = 256;
 constexpr int kLdsStride = kBlock + 1;
 bool g_use_persistent = true;  // LM: false selects the one-voxel-per-lane kernel (T2FIT_ONE_SHOT=1)
 int g_refill_min = 0;           // > 0 overrides the per-solver refill batch (T2FIT_REFILL_MIN)
+#ifndef T2_SAMPLE_LOAD
+#define T2_SAMPLE_LOAD(p) (*(p))  // A/B: -DT2_SAMPLE_LOAD(p)=__builtin_nontemporal_load(p), profiles/r02_exp42_nt_loads.txt
+#endif
 #ifndef T2_WAVE_HINT
 #define T2_WAVE_HINT 2
 #endif
@@ -522,8 +525,11 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
 #pragma unroll
           for (int j = 0; j < 8; ++j)
             if (i0 + j < n_te)
-              tmp[j] = layout == T2FIT_LAYOUT_TE_MAJOR ? echoes[(int64_t)(i0 + j) * n_vox + v]
-                                                       : echoes[v * n_te + (i0 + j)];
+              // (plain loads.  Non-temporal ones keep more of the half-written map lines of the voxels still being
+              // fitted in L2 -- LM float32 writes 313 instead of 425 MB per volume -- but every 128-byte line of samples
+              // is then fetched once per refill that touches it: 1.7 x the reads, 4 % slower)
+              tmp[j] = T2_SAMPLE_LOAD(layout == T2FIT_LAYOUT_TE_MAJOR ? &echoes[(int64_t)(i0 + j) * n_vox + v]
+                                                                      : &echoes[v * n_te + (i0 + j)]);
 #pragma unroll
           for (int j = 0; j < 8; ++j)
             if (i0 + j < n_te) {

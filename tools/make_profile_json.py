@@ -1,5 +1,5 @@
 """Turn the per-kernel PMC summaries of a profile round (gpurun_out/pmc_<tag>_{lbfgsb,lmf32,loglin}.txt, written by
-tools/profile_final.sh) into profiles/traffic.json (HBM bytes per launch) and profiles/instr_mix.json (VALU instruction
+tools/profile_r02.sh) into profiles/traffic.json (HBM bytes per launch) and profiles/instr_mix.json (VALU instruction
 counts per launch), which bench.py reads for `roofline.traffic` and the `alu` view.
 
     python tools/make_profile_json.py <tag>
@@ -11,7 +11,7 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 KEYS = {"lbfgsb": "gaussian_rician/lbfgsb/f64/256x256x256x8", "lmf32": "gaussian_rician/lm/f32/256x256x256x8",
-        "loglin": "gaussian/loglin/f64/256x256x256x8"}
+        "lmf64": "gaussian_rician/lm/f64/256x256x256x8", "loglin": "gaussian/loglin/f64/256x256x256x8"}
 
 
 def read(name):
@@ -39,6 +39,8 @@ traffic = {"_comment": "HBM bytes per launch of the dominant kernel, 1 x MI355X,
 mix = {"_comment": "VALU wave-instructions per launch by class (rocprofv3 --pmc, own passes), 256^3 x 8 TE, mask fill 0.44; "
                    "lanes_active = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)."}
 for name, key in KEYS.items():
+    if not os.path.exists(os.path.join(REPO, "gpurun_out", f"pmc_{tag}_{name}.txt")):
+        continue
     c = read(name)
     if name == "loglin":  # echo planes read 16 B per lane (reported 1/2), the mask 4 B per lane
         mask_reported = n / cal4
