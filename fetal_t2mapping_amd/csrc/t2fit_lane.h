@@ -105,6 +105,18 @@ T2_HD double t2_fdiv(double a, double b) { return a / b; }
 T2_HD double t2_rcp_for_div(double b) { return 1.0 / b; }
 #endif
 T2_HD double t2_rsqrt(double x) { return 1.0 / sqrt(x); }
+// 1 / sqrt(x) to ~1 ulp for x > 0 (v_rsq_f64 seed, two Newton steps), same use as t2_fast_rcp
+#if defined(__HIP_DEVICE_COMPILE__)
+T2_HD double t2_fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = fma(fma(-hx * y, y, 0.5), y, y);
+  y = fma(fma(-hx * y, y, 0.5), y, y);
+  return y;
+}
+#else
+T2_HD double t2_fast_rsqrt(double x) { return 1.0 / sqrt(x); }
+#endif
 T2_HD double t2_rcp(double x) { return 1.0 / x; }
 T2_HD float t2_sqrt(float x) { return sqrtf(x); }
 

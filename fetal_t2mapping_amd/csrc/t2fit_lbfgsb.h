@@ -486,7 +486,7 @@ struct Lbfgsb {
       T2_UNROLL
       for (int i = 0; i < N; ++i) { sn[i] = hs(pn, i); yn[i] = hy(pn, i); }
       double bs[N];
-      double sbs = 0.0, ys = 0.0;
+      double sbs = 0.0;
       T2_UNROLL
       for (int i = 0; i < N; ++i) {
         double a = 0.0;
@@ -495,15 +495,16 @@ struct Lbfgsb {
         bs[i] = a;
       }
       T2_UNROLL
-      for (int i = 0; i < N; ++i) { sbs = fma(sp[i], bs[i], sbs); ys = fma(yp[i], sp[i], ys); }
-      const double rys = t2_fast_rcp(ys), rsbs = t2_fast_rcp(sbs);
-      double ty[N], tb[N];
+      for (int i = 0; i < N; ++i) sbs = fma(sp[i], bs[i], sbs);
+      const double rsbs = t2_fast_rcp(sbs);
+      double tb[N];
       T2_UNROLL
-      for (int i = 0; i < N; ++i) { ty[i] = yp[i] * rys; tb[i] = bs[i] * rsbs; }
+      for (int i = 0; i < N; ++i) tb[i] = bs[i] * rsbs;
+      // (the ring holds y / sqrt(y's): the rank-one term y y' / (y's) needs no scaling here -- digest())
       T2_UNROLL
       for (int i = 0; i < N; ++i)
         T2_UNROLL
-        for (int j = i; j < N; ++j) U[i][j] = fma(yp[i], ty[j], fma(-bs[i], tb[j], U[i][j]));
+        for (int j = i; j < N; ++j) U[i][j] = fma(yp[i], yp[j], fma(-bs[i], tb[j], U[i][j]));
       T2_UNROLL
       for (int i = 0; i < N; ++i) { sp[i] = sn[i]; yp[i] = yn[i]; }
     }
@@ -649,18 +650,19 @@ struct Lbfgsb {
         if (fr[i] && fr[j]) A[i][j] = B[i][j];
     double rr[3] = {r[0], r[1], N == 3 ? r[N - 1] : 0.0};
     if (N == 2) rr[2] = 0.0;
-    const double d0 = A[0][0];
-    const double l10 = t2_fdiv(A[1][0], d0), l20 = t2_fdiv(A[2][0], d0);
-    const double d1 = fma(-l10, A[1][0], A[1][1]);
+    // (one reciprocal per pivot, applied by multiplication: six quotients of this block share three divisors)
+    const double d0 = A[0][0], r0 = t2_fast_rcp(d0);
+    const double l10 = A[1][0] * r0, l20 = A[2][0] * r0;
+    const double d1 = fma(-l10, A[1][0], A[1][1]), r1 = t2_fast_rcp(d1);
     const double a21 = fma(-l20, A[1][0], A[2][1]);
-    const double l21 = t2_fdiv(a21, d1);
-    const double d2 = fma(-l21, a21, fma(-l20, A[2][0], A[2][2]));
+    const double l21 = a21 * r1;
+    const double d2 = fma(-l21, a21, fma(-l20, A[2][0], A[2][2])), r2 = t2_fast_rcp(d2);
     // (no early exit on a non-positive pivot: the step is computed anyway -- NaN or nonsense then, thrown away by the
     // caller, which begins the iteration again -- so that this is one straight block)
     const bool pos_def = d0 > 0.0 && d1 > 0.0 && d2 > 0.0;
     const double y0 = rr[0], y1 = fma(-l10, y0, rr[1]), y2 = fma(-l21, y1, fma(-l20, y0, rr[2]));
-    const double u2 = t2_fdiv(y2, d2), u1 = fma(-l21, u2, t2_fdiv(y1, d1));
-    const double u0 = fma(-l20, u2, fma(-l10, u1, t2_fdiv(y0, d0)));
+    const double u2 = y2 * r2, u1 = fma(-l21, u2, y1 * r1);
+    const double u0 = fma(-l20, u2, fma(-l10, u1, y0 * r0));
     du[0] = u0; du[1] = u1;
     if (N == 3) du[N - 1] = u2;
     // projected Newton point
@@ -794,6 +796,10 @@ struct Lbfgsb {
     T2_UNROLL
     for (int i = 0; i < N; ++i) dn[i] = d[i] * stp;
     const double theta_n = t2_fdiv(rr, dr);
+    // the pair is stored as (s, y / sqrt(y's)): B is rebuilt from the whole ring at every iteration, and this way the
+    // rank-one term of each update is a plain outer product (three multiplications, a dot product and a reciprocal
+    // less per pair and iteration); theta keeps the unscaled y
+    const double rsy = t2_fast_rsqrt(dr);
     const bool iterate_on = newit && !out_of_budget && !converged;
     const bool store_pair = iterate_on && !(dr <= epsmch * ddum);  // else: curvature too small, skip the update
     // -- keep what belongs to this lane's state --
@@ -818,7 +824,7 @@ struct Lbfgsb {
         col = M - 1;
       }
       T2_UNROLL
-      for (int i = 0; i < N; ++i) { hs(col, i) = dn[i]; hy(col, i) = rn[i]; }
+      for (int i = 0; i < N; ++i) { hs(col, i) = dn[i]; hy(col, i) = rn[i] * rsy; }
       ++col;
       theta = theta_n;
     }
