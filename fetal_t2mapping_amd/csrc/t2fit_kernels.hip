@@ -309,7 +309,7 @@ template <int MODEL, int NTE = 0> struct LbfgsbLane {
   using Solver = Lbfgsb<MODEL, NTE>;
   static constexpr int NP = Solver::N;
   static constexpr int kNte = NTE;  // > 0: the echo count is a compile-time constant (the refill loops flatten too)
-  static constexpr int kHistDoubles = 2 * Solver::M * Solver::N;  // correction pairs, per lane, in LDS
+  static constexpr int kHistDoubles = Solver::M * Solver::PAIR;  // correction pairs, per lane, in LDS
   static constexpr int kWavesPerSimd = 1;
   // one-wave workgroups, two waves on a SIMD: the Rician lane (i0e) needs more than the 256 registers that allows
   static constexpr bool kWaveWgOk = MODEL != T2FIT_MODEL_RICIAN;
@@ -861,10 +861,11 @@ hipError_t launch_persistent(unsigned grid, size_t lds_samples, hipStream_t st, 
   const bool extras = dm.r2 || dm.se || dm.fun || dm.nit || dm.status || dm.xd || dm.fund;
 #if !defined(T2_PHASE_STAMPS)
   if constexpr (kLargeOnly && A::kHistDoubles > 0 && A::kWaveWgOk) {
-    // One-wave workgroups.  The lane's correction pairs (480 B with three parameters, 320 B with two) cap a CU's
-    // 160 KiB of LDS at 341 lanes: four waves as one 256-lane workgroup, but FIVE as one-wave workgroups (eight with
-    // two parameters) -- the lane fits 256 registers, so one SIMD (all four) of each CU then interleaves two waves.
-    // Nothing but the pairs is in LDS: the samples are in registers (echo-count specialisation), the voxel queue too.
+    // One-wave workgroups.  The lane's correction pairs (400 B with three parameters, 240 B with two: s is kept as a
+    // direction, t2fit_lbfgsb.h load_s) cap a CU's 160 KiB of LDS at 409 lanes: four waves as one 256-lane workgroup,
+    // but SIX as one-wave workgroups (eight with two parameters) -- the lane fits 256 registers, so two SIMDs (all
+    // four) of each CU then interleave two waves.  Nothing but the pairs is in LDS: the samples are in registers
+    // (echo-count specialisation), the voxel queue too.
     if (g_wave_wg) {
       // (T2FIT_WAVE_WG=2 / 3: the same register-queue code in workgroups of 256 / 128 lanes -- diagnostic builds only)
       auto k64 = extras ? fit_persistent_kernel<A, kChunkSmall, false, kWaveHint, true, 64, true>

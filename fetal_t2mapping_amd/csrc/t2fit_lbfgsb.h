@@ -302,6 +302,7 @@ template <int MODEL, int NTE = 0>
 struct Lbfgsb {
   static constexpr int N = MODEL == T2FIT_MODEL_GAUSSIAN ? 2 : 3;
   static constexpr int M = 10;
+  static constexpr int PAIR = 2 * N - 1;  // doubles per correction pair in the ring (see load_s / store_s)
 
   double lb[N], ub[N];              // box
   double x[N], g[N], f;             // current evaluation point, objective, FD gradient
@@ -313,6 +314,7 @@ struct Lbfgsb {
   // lane for n = 3), which is what keeps the solver state within the VGPR budget.
   double* hist;
   int hstride, head;
+  uint32_t piv;  // two bits per ring slot: which component of that slot's s is the implicit 1
   int iwhere[N];
   int col, nit, nfev, ifun;
   uint8_t status;
@@ -458,8 +460,48 @@ struct Lbfgsb {
     return nrm;
   }
 
-  T2_HD double& hs(int p, int i) const { return hist[((((head + p) % M) * 2) * N + i) * hstride]; }
-  T2_HD double& hy(int p, int i) const { return hist[((((head + p) % M) * 2 + 1) * N + i) * hstride]; }
+  // Ring slot of pair number p (0 = oldest): PAIR = 2N - 1 doubles.  The BFGS update does not change when s is
+  // scaled, so s is kept as a DIRECTION: its component of largest magnitude is taken to be 1 (which one: two bits per
+  // physical slot in `piv`) and only the N - 1 ratios to it are stored; then the N components of y / sqrt(y's).  Ten
+  // pairs are 400 instead of 480 bytes per lane with three parameters -- what lets a CU hold six waves instead of five.
+  T2_HD int slot_of(int p) const { return (head + p) % M; }
+  T2_HD double& hratio(int q, int e) const { return hist[(q * PAIR + e) * hstride]; }
+  T2_HD double& hy(int q, int i) const { return hist[(q * PAIR + (N - 1) + i) * hstride]; }
+  T2_HD void load_s(int q, double* sv) const {
+    const unsigned pv = (piv >> (2 * q)) & 3u;
+    const double a = hratio(q, 0);
+    if constexpr (N == 3) {
+      const double b = hratio(q, 1);
+      sv[0] = pv == 0u ? 1.0 : a;
+      sv[1] = pv == 1u ? 1.0 : (pv == 0u ? a : b);
+      sv[2] = pv == 2u ? 1.0 : b;
+    } else {
+      sv[0] = pv == 0u ? 1.0 : a;
+      sv[1] = pv == 1u ? 1.0 : a;
+    }
+  }
+  T2_HD void store_s(int q, const double* sv) {
+    // pivot: the component of largest magnitude (the first of equals); s is not zero here (y's > 0)
+    unsigned pv = 0u;
+    double big = t2_abs(sv[0]), piv_val = sv[0];
+    T2_UNROLL
+    for (int i = 1; i < N; ++i) {
+      const bool more = t2_abs(sv[i]) > big;
+      big = more ? t2_abs(sv[i]) : big;
+      piv_val = more ? sv[i] : piv_val;
+      pv = more ? (unsigned)i : pv;
+    }
+    const double r = t2_rcp_for_div(piv_val);
+    if constexpr (N == 3) {
+      const double na = pv == 0u ? sv[1] : sv[0], nb = pv == 2u ? sv[1] : sv[2];
+      hratio(q, 0) = t2_div_by_rcp(na, piv_val, r);
+      hratio(q, 1) = t2_div_by_rcp(nb, piv_val, r);
+    } else {
+      const double na = pv == 0u ? sv[1] : sv[0];
+      hratio(q, 0) = t2_div_by_rcp(na, piv_val, r);
+    }
+    piv = (piv & ~(3u << (2 * q))) | (pv << (2 * q));
+  }
 
   // B = theta*I updated by the stored pairs, oldest first (BFGS recursion; B stays symmetric, so
   // only the upper triangle is computed).  The next pair is fetched from the ring while the
@@ -475,16 +517,19 @@ struct Lbfgsb {
       for (int j = 0; j < N; ++j) U[i][j] = i == j ? theta : 0.0;
     double sp[N], yp[N];
     if (col > 0) {
+      const int q0 = slot_of(0);
+      load_s(q0, sp);
       T2_UNROLL
-      for (int i = 0; i < N; ++i) { sp[i] = hs(0, i); yp[i] = hy(0, i); }
+      for (int i = 0; i < N; ++i) yp[i] = hy(q0, i);
     }
     T2_UNROLL
     for (int p = 0; p < M; ++p) {
       if (p >= col) continue;
       double sn[N], yn[N];
-      const int pn = p + 1 < col ? p + 1 : p;
+      const int qn = slot_of(p + 1 < col ? p + 1 : p);
+      load_s(qn, sn);
       T2_UNROLL
-      for (int i = 0; i < N; ++i) { sn[i] = hs(pn, i); yn[i] = hy(pn, i); }
+      for (int i = 0; i < N; ++i) yn[i] = hy(qn, i);
       double bs[N];
       double sbs = 0.0;
       T2_UNROLL
@@ -728,6 +773,7 @@ struct Lbfgsb {
     hist = hist_;
     hstride = hstride_;
     head = 0;
+    piv = 0u;
     T2_UNROLL
     for (int i = 0; i < N; ++i) {
       lb[i] = lb_[i];
@@ -823,8 +869,10 @@ struct Lbfgsb {
         head = (head + 1) % M;
         col = M - 1;
       }
+      const int q = slot_of(col);
+      store_s(q, dn);
       T2_UNROLL
-      for (int i = 0; i < N; ++i) { hs(col, i) = dn[i]; hy(col, i) = rn[i] * rsy; }
+      for (int i = 0; i < N; ++i) hy(q, i) = rn[i] * rsy;
       ++col;
       theta = theta_n;
     }
@@ -953,7 +1001,7 @@ struct Lbfgsb {
 template <int MODEL>
 T2_HD void lbfgsb_solve(const ObjCtx& c, const double* lb, const double* ub, LaneResult& out) {
   Lbfgsb<MODEL> s;
-  double hist[2 * Lbfgsb<MODEL>::M * Lbfgsb<MODEL>::N] = {};
+  double hist[Lbfgsb<MODEL>::M * Lbfgsb<MODEL>::PAIR] = {};
   s.init(c.P->x0, lb, ub, hist, 1);
   do {
     s.eval(c);
