@@ -397,7 +397,7 @@ def main():
                          "bytes_per_voxel": bytes_per_voxel, "voxels_per_launch": n_vox,
                          "note": ("one streaming pass, HBM bound" if a.solver == "loglin" else
                                   "the fit is float64 VALU-issue bound (about 4500 wave instructions per evaluation round; "
-                                  "its LDS-resident correction pairs allow five waves per CU), not HBM bound: see DESIGN.md "
+                                  "its LDS-resident correction pairs allow six waves per CU), not HBM bound: see DESIGN.md "
                                   "section 6 and `alu`")},
         }
         alu = alu_view(key, k_ms) if n_vox == n_vol else None
