@@ -95,12 +95,13 @@ def parse():
     p.add_argument("--no-gather", action="store_true", help="skip the all-gather of the maps (N > 1)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration (0 = skip)")
     p.add_argument("--no-also", action="store_true", help="skip the secondary (converged LM float32) measurement")
-    p.add_argument("--reserve-cus", type=int, default=8,
-                   help="N > 1 with the all-gather: CUs the persistent fit kernel leaves free for RCCL's kernels (0 = none). "
-                        "Measured on one GPU (profiles/r02_overlap_*.jsonl): kernels that need little LDS run beside the fit "
-                        "even with no CU left free, but the fit's workgroups hold 153 of a CU's 160 KiB of LDS, which a "
-                        "collective's kernel does not fit beside; 8 free CUs cost the fit 3 %% and are a bet, not a measurement "
-                        "(no multi-GPU node was available to the build)")
+    p.add_argument("--reserve-cus", type=int, default=0,
+                   help="N > 1 with the all-gather: CUs the persistent fit kernel leaves free for RCCL's kernels in the timed "
+                        "steps (0 = none, the default).  Whether that pays cannot be measured on one GPU "
+                        "(profiles/r02_overlap_*.jsonl: kernels that need little LDS run beside the fit anyway, the fit's "
+                        "workgroups hold 150 of a CU's 160 KiB), so the N > 1 run times the other setting too, after the "
+                        "timed steps, and reports it beside `value` as `reserve_cus_ab`")
+    p.add_argument("--reserve-cus-ab", type=int, default=8, help="the other setting measured for `reserve_cus_ab` (N > 1)")
     return p.parse_args()
 
 
@@ -218,13 +219,11 @@ def main():
     packed = [torch.empty((4, n_vox), dtype=torch.float32, device=dev) for _ in range(2 if do_gather else 1)]
     gathered = [torch.empty((world, 4, n_vox), dtype=torch.float32, device=dev) for _ in range(2)] if do_gather else None
     ordered = torch.empty((4, world * n_vox), dtype=torch.float32, device=dev) if (do_gather and src_index is not None) else None
-    reserved = 0
-    if do_gather and a.solver == "lbfgsb" and a.reserve_cus > 0 and "T2FIT_PERSISTENT_BLOCKS" not in os.environ:
-        # The reference-trajectory kernel is persistent with one workgroup per CU (its LDS-resident history fills the
-        # CU).  T2FIT_RESERVE_CUS makes the library launch it over (CUs - reserve) workgroups so that RCCL's kernels
-        # find free CUs while it runs.  The library reads the variable once, at its first launch.
-        reserved = a.reserve_cus
-        os.environ["T2FIT_RESERVE_CUS"] = str(reserved)
+    # The reference-trajectory kernel is persistent and its workgroups fill every CU's LDS; t2fit_set_reserve_cus makes
+    # the library launch it over (CUs - reserve) CUs so that RCCL's kernels find free CUs while it runs.
+    can_reserve = do_gather and a.solver == "lbfgsb" and "T2FIT_PERSISTENT_BLOCKS" not in os.environ
+    reserved = a.reserve_cus if can_reserve else 0
+    lib.t2fit_set_reserve_cus(reserved)
     maps_b = []
     for pk in packed:
         mb = _abi.T2FitMaps()
@@ -293,6 +292,28 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    # the other reserve-CUs setting, same steps, after the timed region (N > 1 only): reported, never `value`
+    reserve_ab = None
+    if can_reserve and a.reserve_cus_ab != reserved and a.reserve_cus_ab >= 0:
+        lib.t2fit_set_reserve_cus(a.reserve_cus_ab)
+        step(False)
+        drain()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            step(False)
+        drain()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t1
+        tt = torch.tensor([e2], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        reserve_ab = {"cus_left_free_for_rccl": a.reserve_cus_ab, "ms_per_step": round(float(tt.item()) / a.steps * 1e3, 4)}
+        lib.t2fit_set_reserve_cus(reserved)
 
     # strong scaling self-check (outside the timed region): the maps every rank now holds for the whole volume are,
     # bit for bit, the maps of a single-GPU fit of that volume (rank 0 fits it alone and compares)
@@ -400,6 +421,10 @@ def main():
                                   "its LDS-resident correction pairs allow six waves per CU), not HBM bound: see DESIGN.md "
                                   "section 6 and `alu`")},
         }
+        if reserve_ab is not None:
+            reserve_ab["value"] = round(total_vox / (reserve_ab["ms_per_step"] * 1e-3) / 1e6, 3)
+            reserve_ab["note"] = "the same steps with the other --reserve-cus setting, timed after the steps of `value`"
+            out["reserve_cus_ab"] = reserve_ab
         alu = alu_view(key, k_ms) if n_vox == n_vol else None
         if alu is not None:
             out["alu"] = alu

@@ -48,6 +48,7 @@ constexpr int kWaveHint = T2_WAVE_HINT;  // occupancy the register allocator / s
 int g_waves_per_cu = 0;         // T2FIT_WAVES_PER_CU: cap of the above (A/B runs)
 int g_wave_wg = 1;         // one-wave workgroups for the large-volume L-BFGS-B kernels (T2FIT_WAVE_WG=0: 256-lane workgroups)
 int g_persistent_blocks = 2048;  // grid of the persistent kernel (T2FIT_PERSISTENT_BLOCKS overrides)
+bool g_reserve_set = false;      // t2fit_set_reserve_cus() was called: it wins over the environment
 int g_reserve_cus = 0;           // T2FIT_RESERVE_CUS: CUs the one-workgroup-per-CU L-BFGS-B kernel leaves free
 bool g_nte_special = true;       // T2FIT_NTE_SPECIAL=0: always the generic-echo-count lane (A/B switch)
 int g_park_min = 1;              // T2FIT_PARK_MIN: lanes of a wave that must be waiting for begin() before it runs (A/B switch)
@@ -956,7 +957,7 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
     if (const char* e = std::getenv("T2FIT_ONE_SHOT")) g_use_persistent = std::atoi(e) == 0;
     if (const char* e = std::getenv("T2FIT_PERSISTENT_BLOCKS")) g_persistent_blocks = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("T2FIT_REFILL_MIN")) g_refill_min = std::min(64, std::max(1, std::atoi(e)));
-    if (const char* e = std::getenv("T2FIT_RESERVE_CUS")) g_reserve_cus = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("T2FIT_RESERVE_CUS"); e && !g_reserve_set) g_reserve_cus = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("T2FIT_NTE_SPECIAL")) g_nte_special = std::atoi(e) != 0;
     if (const char* e = std::getenv("T2FIT_PARK_MIN")) g_park_min = std::min(64, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("T2FIT_WAVE_WG")) g_wave_wg = std::max(0, std::atoi(e));
@@ -1110,6 +1111,13 @@ int t2fit_device_count(void) {
     return 0;
   }
   return n;
+}
+
+int t2fit_set_reserve_cus(int cus) {
+  const int before = g_reserve_cus;
+  g_reserve_cus = std::max(0, cus);
+  g_reserve_set = true;
+  return before;
 }
 
 int t2fit_set_timing(int enabled) {

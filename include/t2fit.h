@@ -205,6 +205,13 @@ int t2fit_label_stats_dev(const float *map_dev, const int32_t *label_dev, int64_
 int t2fit_set_timing(int enabled);
 double t2fit_last_kernel_ms(void);
 
+/* Multi-GPU tuning: the reference-trajectory fit is a persistent kernel whose workgroups fill every CU's LDS, so a
+ * collective's kernel on another stream (RCCL's all-gather of the previous maps) may not find room before it drains.
+ * `cus` > 0 makes the fit leave that many CUs unoccupied (costs cus/256 of its speed); 0 = use them all (default; the
+ * environment variable T2FIT_RESERVE_CUS sets the initial value).  Returns the previous setting.  No reference
+ * counterpart (the reference is single-process). */
+int t2fit_set_reserve_cus(int cus);
+
 const char *t2fit_last_error(void);
 int t2fit_abi_version(void);
 

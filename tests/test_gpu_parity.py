@@ -1042,6 +1042,9 @@ def test_bench_strong_scaling_control_flow_two_ranks_one_gpu(t2, partition):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["gathered_maps_equal_single_gpu_fit"] is True
     assert d["config"]["voxels_total"] == 37 * 96 * 100 and d["value"] > 0 and d["fitted_value"] < d["value"]
+    # the all-gather steps are timed with no CU held back for RCCL and, after the timed region, with 8 held back
+    assert d["config"]["cus_left_free_for_rccl"] == 0 and d["reserve_cus_ab"]["cus_left_free_for_rccl"] == 8
+    assert d["reserve_cus_ab"]["value"] > 0
 
 
 def test_iteration_traces_match_reference_callbacks(t2):
