@@ -101,6 +101,10 @@ def parse():
                         "(profiles/r02_overlap_*.jsonl: kernels that need little LDS run beside the fit anyway, the fit's "
                         "workgroups hold 150 of a CU's 160 KiB), so the N > 1 run times the other setting too, after the "
                         "timed steps, and reports it beside `value` as `reserve_cus_ab`")
+    p.add_argument("--pipeline", choices=["auto", "on", "off"], default="auto",
+                   help="consecutive steps alternate between two streams, so that the drain of one fit launch (a few waves "
+                        "finishing their last voxels, about 1 ms whatever the share size) overlaps the start of the next: "
+                        "auto = on for N > 1 (where a rank's share is small and the drain is a third of the launch), off for N = 1")
     p.add_argument("--reserve-cus-ab", type=int, default=8, help="the other setting measured for `reserve_cus_ab` (N > 1)")
     return p.parse_args()
 
@@ -216,9 +220,12 @@ def main():
     # stream, xGMI) overlaps the fit kernel of step i+1; a buffer is reused only after the gather that
     # read it has been waited for on the compute stream.
     do_gather = world > 1 and not a.no_gather
-    packed = [torch.empty((4, n_vox), dtype=torch.float32, device=dev) for _ in range(2 if do_gather else 1)]
+    pipelined = a.pipeline == "on" or (a.pipeline == "auto" and world > 1)
+    n_buf = 2 if (do_gather or pipelined) else 1
+    packed = [torch.empty((4, n_vox), dtype=torch.float32, device=dev) for _ in range(n_buf)]
     gathered = [torch.empty((world, 4, n_vox), dtype=torch.float32, device=dev) for _ in range(2)] if do_gather else None
-    ordered = torch.empty((4, world * n_vox), dtype=torch.float32, device=dev) if (do_gather and src_index is not None) else None
+    ordered = ([torch.empty((4, world * n_vox), dtype=torch.float32, device=dev) for _ in range(2)]
+               if (do_gather and src_index is not None) else None)
     # The reference-trajectory kernel is persistent and its workgroups fill every CU's LDS; t2fit_set_reserve_cus makes
     # the library launch it over (CUs - reserve) CUs so that RCCL's kernels find free CUs while it runs.
     can_reserve = do_gather and a.solver == "lbfgsb" and "T2FIT_PERSISTENT_BLOCKS" not in os.environ
@@ -231,44 +238,49 @@ def main():
         maps_b.append(mb)
     maps = maps_b[0]
     pending = [None, None]
-    stream = torch.cuda.current_stream()
-    st = C.c_void_p(stream.cuda_stream)
+    # step i runs on stream i % 2 when pipelined (its fit, its all-gather dependency, its reordering), else on the current stream
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()] if pipelined else [torch.cuda.current_stream()]
     lib.t2fit_set_timing(1)
     kernel_ms = []
     step_no = [0]
+
+    def stream_of(b):
+        return streams[b % len(streams)]
 
     def reorder(b):
         """strong scaling, cyclic partition: the gathered chunk table back into voxel order (one gather of 64 KiB rows)."""
         if ordered is not None:
             slots = n_vox // t2dist.CHUNK
             by_chunk = gathered[b].view(world, 4, slots, t2dist.CHUNK).permute(1, 0, 2, 3).reshape(4, world * slots, t2dist.CHUNK)
-            torch.index_select(by_chunk, 1, src_index, out=ordered.view(4, world * slots, t2dist.CHUNK))
+            torch.index_select(by_chunk, 1, src_index, out=ordered[b].view(4, world * slots, t2dist.CHUNK))
 
     def step(record):
         b = step_no[0] % len(packed)
         step_no[0] += 1
-        if pending[b] is not None:
-            pending[b].wait()  # stream-side wait: buffer b is free again
-            reorder(b)
-            pending[b] = None
-        check(lib.t2fit_volume_dev(C.byref(cfg), echoes.data_ptr(), _abi.LAYOUT_TE_MAJOR, mask.data_ptr(), n_vox,
-                                   C.byref(maps_b[b]), st))
-        if do_gather:
-            if rehearsal:
-                parts = [torch.empty((4, n_vox), dtype=torch.float32) for _ in range(world)]
-                dist.all_gather(parts, packed[b].cpu())
-                gathered[b].copy_(torch.stack(parts))
+        with torch.cuda.stream(stream_of(b)):
+            if pending[b] is not None:
+                pending[b].wait()  # stream-side wait: buffer b is free again
                 reorder(b)
-            else:
-                pending[b] = dist.all_gather_into_tensor(gathered[b].view(-1), packed[b].view(-1), async_op=True)
-        if record:
+                pending[b] = None
+            check(lib.t2fit_volume_dev(C.byref(cfg), echoes.data_ptr(), _abi.LAYOUT_TE_MAJOR, mask.data_ptr(), n_vox,
+                                       C.byref(maps_b[b]), C.c_void_p(stream_of(b).cuda_stream)))
+            if do_gather:
+                if rehearsal:
+                    parts = [torch.empty((4, n_vox), dtype=torch.float32) for _ in range(world)]
+                    dist.all_gather(parts, packed[b].cpu())
+                    gathered[b].copy_(torch.stack(parts))
+                    reorder(b)
+                else:
+                    pending[b] = dist.all_gather_into_tensor(gathered[b].view(-1), packed[b].view(-1), async_op=True)
+        if record and not pipelined:
             kernel_ms.append(lib.t2fit_last_kernel_ms())  # syncs on the kernel's stop event only
 
     def drain():
         for b in range(2):
             if pending[b] is not None:
-                pending[b].wait()
-                reorder(b)
+                with torch.cuda.stream(stream_of(b)):
+                    pending[b].wait()
+                    reorder(b)
                 pending[b] = None
 
     for _ in range(a.warmup):
@@ -288,6 +300,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if pipelined:  # kernel times of the last timed launches, read now that they are done (no stall inside the region)
+        kernel_ms = [lib.t2fit_kernel_ms(k) for k in range(min(a.steps, 16))]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -323,12 +337,13 @@ def main():
         alone = torch.empty((4, n_vol), dtype=torch.float32, device=dev)
         ma = _abi.T2FitMaps()
         ma.t2, ma.k, ma.sigma, ma.res = (alone[j].data_ptr() for j in range(4))
-        check(lib.t2fit_volume_dev(C.byref(cfg), e_all.data_ptr(), _abi.LAYOUT_TE_MAJOR, m_all.data_ptr(), n_vol, C.byref(ma), st))
+        check(lib.t2fit_volume_dev(C.byref(cfg), e_all.data_ptr(), _abi.LAYOUT_TE_MAJOR, m_all.data_ptr(), n_vol, C.byref(ma),
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         torch.cuda.synchronize()
         last = (step_no[0] - 1) % len(packed)
         if ordered is not None:
             reorder(last)
-            whole = ordered[:, :n_vol]
+            whole = ordered[last][:, :n_vol]
         else:
             whole = gathered[last].permute(1, 0, 2).reshape(4, world * n_vox)[:, :n_vol]
         verified = bool(((whole == alone) | (whole.isnan() & alone.isnan())).all().item())
@@ -336,6 +351,8 @@ def main():
 
     # secondary measurements, same data on this rank: the converged bounded-LM solver (north_star's "per-lane
     # Levenberg-Marquardt") in float32 and in the reference's float64, and the closed form; never `value`
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
     def measure(cfg_x):
         """Mean kernel time (HIP events on the launch stream) and mean wall time per launch of one more solver."""
         n2 = max(3, min(10, a.steps))
@@ -407,6 +424,7 @@ def main():
                        "masked_voxels_total": total_masked, "voxels_rank0": n_vox, "masked_voxels_rank0": masked_mine,
                        "parallelism": part + (" + all-gather of 4 maps (overlapped with the next fit)" if do_gather else ""),
                        "cus_left_free_for_rccl": reserved,
+                       "steps_pipelined_over_two_streams": pipelined,
                        "metric_note": "BASELINE.json words the metric '3-param LM'; the reference's solver is scipy L-BFGS-B "
                                       "(SURVEY.md F1) and `value` is the solver that reproduces the reference's maps; the "
                                       "converged LM kernel north_star describes is measured in the same run under `also` "
@@ -415,6 +433,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel": "loglin_volume_kernel" if a.solver == "loglin" else "fit_persistent_kernel",
                          "kernel_ms": round(k_ms, 4),
+                         "kernel_ms_note": ("steps alternate between two streams: a launch's start-to-end time includes the "
+                                            "drain of the launch before it, which it overlaps" if pipelined else None),
                          "bytes_per_voxel": bytes_per_voxel, "voxels_per_launch": n_vox,
                          "note": ("one streaming pass, HBM bound" if a.solver == "loglin" else
                                   "the fit is float64 VALU-issue bound (about 4500 wave instructions per evaluation round; "

@@ -55,8 +55,12 @@ int g_park_min = 1;              // T2FIT_PARK_MIN: lanes of a wave that must be
 
 thread_local std::string g_err;
 thread_local bool g_timing = false;
-thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
-thread_local bool g_ev_valid = false;
+// start / stop events of the last kEvRing timed launches (a caller that pipelines launches over several streams reads a
+// launch's time a few launches later, when it is long done, instead of stalling on the one just queued)
+constexpr int kEvRing = 16;
+thread_local hipEvent_t g_ev0[kEvRing] = {}, g_ev1[kEvRing] = {};
+thread_local long g_ev_count = 0;   // timed launches so far
+thread_local int g_ev_slot = 0;     // ring slot of the launch being queued
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -978,11 +982,12 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
     T2_HIP(hipMemsetAsync(counter, 0, kCounterWords * sizeof(unsigned long long), st));
   }
   if (g_timing) {
-    if (!g_ev0) {
-      T2_HIP(hipEventCreate(&g_ev0));
-      T2_HIP(hipEventCreate(&g_ev1));
+    g_ev_slot = (int)(g_ev_count % kEvRing);
+    if (!g_ev0[g_ev_slot]) {
+      T2_HIP(hipEventCreate(&g_ev0[g_ev_slot]));
+      T2_HIP(hipEventCreate(&g_ev1[g_ev_slot]));
     }
-    T2_HIP(hipEventRecord(g_ev0, st));
+    T2_HIP(hipEventRecord(g_ev0[g_ev_slot], st));
   }
   if (persistent) {
     // one workgroup per CU slot; not required to be co-resident (work comes from an atomic queue)
@@ -1029,8 +1034,8 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
 #undef T2_PERSIST
     if (pe != hipSuccess) return fail(T2FIT_E_HIP, std::string("persistent fit launch: ") + hipGetErrorString(pe));
     if (g_timing) {  // the timed kernel is the fit; the epilogue pass is a separate, HBM-bound launch
-      T2_HIP(hipEventRecord(g_ev1, st));
-      g_ev_valid = true;
+      T2_HIP(hipEventRecord(g_ev1[g_ev_slot], st));
+      ++g_ev_count;
     }
     hipLaunchKernelGGL(residuals_kernel, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox,
                        (const float*)dm.t2, (const float*)dm.k, (const float*)dm.sigma, dm.res, dm.r2, dm.se);
@@ -1044,8 +1049,8 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
   }
   T2_HIP(hipGetLastError());
   if (g_timing && !persistent) {
-    T2_HIP(hipEventRecord(g_ev1, st));
-    g_ev_valid = true;
+    T2_HIP(hipEventRecord(g_ev1[g_ev_slot], st));
+    ++g_ev_count;
   }
 #if defined(T2_PHASE_STAMPS)
   if (counter && cfg->solver == T2FIT_SOLVER_LBFGSB) {
@@ -1122,17 +1127,20 @@ int t2fit_set_reserve_cus(int cus) {
 
 int t2fit_set_timing(int enabled) {
   g_timing = enabled != 0;
-  g_ev_valid = false;
+  g_ev_count = 0;
   return T2FIT_OK;
 }
 
-double t2fit_last_kernel_ms(void) {
-  if (!g_ev_valid) return -1.0;
-  if (hipEventSynchronize(g_ev1) != hipSuccess) return -1.0;
+double t2fit_kernel_ms(int launches_ago) {
+  if (launches_ago < 0 || launches_ago >= kEvRing || launches_ago >= g_ev_count) return -1.0;
+  const int slot = (int)((g_ev_count - 1 - launches_ago) % kEvRing);
+  if (hipEventSynchronize(g_ev1[slot]) != hipSuccess) return -1.0;
   float ms = 0.0f;
-  if (hipEventElapsedTime(&ms, g_ev0, g_ev1) != hipSuccess) return -1.0;
+  if (hipEventElapsedTime(&ms, g_ev0[slot], g_ev1[slot]) != hipSuccess) return -1.0;
   return (double)ms;
 }
+
+double t2fit_last_kernel_ms(void) { return t2fit_kernel_ms(0); }
 
 int t2fit_volume_dev(const t2fit_config* cfg, const float* echoes_dev, int layout, const uint8_t* mask_dev,
                      int64_t n_vox, const t2fit_maps* maps, void* stream) {

@@ -199,10 +199,13 @@ int t2fit_residuals_dev(const t2fit_config *cfg, const float *echoes_dev, int la
 int t2fit_label_stats_dev(const float *map_dev, const int32_t *label_dev, int64_t n_vox, int n_labels,
                           double *mean_out, double *std_out, int64_t *count_out, void *stream);
 
-/* Duration in milliseconds of the last fit kernel launched by this thread's most recent
- * t2fit_volume_dev call with timing enabled (t2fit_set_timing(1)); measured with HIP events on
- * the launch stream.  Returns a negative value when unavailable. */
+/* Kernel timing for benchmarks (no reference counterpart).  With timing enabled (t2fit_set_timing(1)) every
+ * t2fit_volume_dev call of this thread records HIP events around its fit kernel on the launch stream.
+ * t2fit_kernel_ms(k): duration in milliseconds of the fit kernel launched k timed calls ago (0 = the most recent;
+ * the last 16 are kept), waiting for that launch to finish if it has not; negative when unavailable.
+ * t2fit_last_kernel_ms() = t2fit_kernel_ms(0). */
 int t2fit_set_timing(int enabled);
+double t2fit_kernel_ms(int launches_ago);
 double t2fit_last_kernel_ms(void);
 
 /* Multi-GPU tuning: the reference-trajectory fit is a persistent kernel whose workgroups fill every CU's LDS, so a
