@@ -138,3 +138,25 @@ extern "C" int hostsim_eval_points(const t2fit_config* cfg, const float* row, do
   else { Lbfgsb<T2FIT_MODEL_RICIAN> s; run(s); }
   return 0;
 }
+
+// The ring's storage form of a correction pair's s (t2fit_lbfgsb.h store_s / load_s): write `n` vectors of `dim`
+// (2 or 3) components through every ring slot and read them back.
+extern "C" int hostsim_pair_roundtrip(int dim, const double* s_in, int64_t n, double* s_out) {
+  if (dim != 2 && dim != 3) return -1;
+  for (int64_t v = 0; v < n; ++v) {
+    double hist[64] = {};
+    const int q = (int)(v % 10);
+    if (dim == 3) {
+      Lbfgsb<T2FIT_MODEL_GAUSSIAN_RICIAN> s;
+      s.hist = hist; s.hstride = 1; s.head = 0; s.piv = 0xfffffu;  // stale bits everywhere: store_s must clear its own
+      s.store_s(q, s_in + 3 * v);
+      s.load_s(q, s_out + 3 * v);
+    } else {
+      Lbfgsb<T2FIT_MODEL_GAUSSIAN> s;
+      s.hist = hist; s.hstride = 1; s.head = 0; s.piv = 0xfffffu;
+      s.store_s(q, s_in + 2 * v);
+      s.load_s(q, s_out + 2 * v);
+    }
+  }
+  return 0;
+}

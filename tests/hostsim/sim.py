@@ -93,3 +93,13 @@ def residuals(cfg, rows, k, t2, sigma):
     L.hostsim_residuals(C.byref(cfg), rows.ctypes.data, rows.shape[0], k.ctypes.data, t2.ctypes.data,
                         sigma.ctypes.data, res.ctypes.data)
     return res
+
+
+def pair_roundtrip(s):
+    """s: (n, 2 or 3) float64 -> what the correction-pair ring hands back for each row (a multiple of it)."""
+    L = lib()
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    out = np.empty_like(s)
+    L.hostsim_pair_roundtrip.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+    assert L.hostsim_pair_roundtrip(s.shape[1], s.ctypes.data, len(s), out.ctypes.data) == 0
+    return out

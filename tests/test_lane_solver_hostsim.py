@@ -140,3 +140,24 @@ def test_lbfgsb_lane_reproduces_the_notebook_known_answer():
     o = sim.fit_rows(cfg, NOTEBOOK_MEAN[None, :])
     assert o["nit"][0] == want[2] == 13 and o["status"][0] == 1
     assert abs(o["x"][0, 1] - want[0][1]) < 1e-3 and abs(o["x"][0, 0] - want[0][0]) < 1e-2
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_correction_pair_ring_keeps_the_direction_of_s(dim):
+    """The ring stores s as a direction -- the component of largest magnitude becomes an implicit 1, the others their
+    ratio to it (t2fit_lbfgsb.h store_s / load_s; the BFGS update does not change when s is scaled).  What comes back
+    must be s divided by that component, every entry to 1 ulp: zeros stay exact zeros, ties take the first component,
+    magnitudes 1e-300 .. 1e300 and mixed signs survive, stale pivot bits of the slot are overwritten."""
+    rng = np.random.default_rng(5)
+    s = rng.normal(size=(4000, dim)) * 10.0 ** rng.integers(-12, 12, size=(4000, dim))
+    s[:200, 0] = 0.0                      # a variable at its bound does not move
+    s[200:300, 1:] = 0.0                  # only the first moves
+    s[300:400] = np.abs(s[300:400, :1])   # ties
+    s[400:420] *= 1e-290
+    s[420:440] *= 1e280
+    got = sim.pair_roundtrip(s)
+    piv = np.argmax(np.abs(s), axis=1)    # first of equals, as in store_s
+    want = s / s[np.arange(len(s)), piv][:, None]
+    assert np.array_equal(got[np.arange(len(s)), piv], np.ones(len(s)))
+    assert np.array_equal(got == 0.0, s == 0.0)
+    assert np.allclose(got, want, rtol=4e-16, atol=0.0)
