@@ -898,6 +898,50 @@ def test_large_volume_kernels_equal_the_small_volume_kernel(t2, fit, n_te, prior
         del whole
 
 
+def test_large_volume_kernels_on_empty_masks_and_bad_samples(t2):
+    """The large-volume kernels' chunk queue on inputs that starve it: a mask that is zero everywhere (every chunk is
+    empty: all maps zero, every status MASKED), a mask with a single voxel at the very end, and a volume in which every
+    16th voxel has a NaN / inf sample or (under --no_prior) a first echo above the k bound -- those voxels end at once with
+    the reference's x = clipped x0 / status 3, or status 4, and their neighbours are fitted as if they were not there."""
+    import torch
+
+    from fetal_t2mapping_amd import _abi, synth
+
+    dev = torch.device("cuda", 0)
+    shape = (24, 256, 256)
+    n = shape[0] * shape[1] * shape[2]
+    echoes, mask, te = synth.brain_volume_torch(shape, 8, synth.SEED_BASE + 12, dev)
+    table = t2.fit_table("gaussian_rician", True)
+    vol = echoes.reshape((8,) + shape)
+    none = t2.fit_volume(vol, torch.zeros_like(mask), te, "gaussian_rician", table, extras=True)
+    assert all(bool((getattr(none, k) == 0).all()) for k in ("t2", "k", "sigma", "res"))
+    assert bool((none.status == _abi.ST_MASKED).all())
+    one = torch.zeros_like(mask)
+    one[-1] = 1
+    last = t2.fit_volume(vol, one, te, "gaussian_rician", table, extras=True)
+    ref = t2.fit_volume(echoes[:, -4096:].contiguous().reshape(8, 1, 1, 4096), one[-4096:].contiguous(), te, "gaussian_rician",
+                        table, extras=True)
+    assert int((last.status.reshape(-1) != _abi.ST_MASKED).sum()) == 1
+    for name in ("t2", "k", "sigma", "res", "nit"):
+        assert _bitwise_equal(getattr(last, name).reshape(-1)[-4096:], getattr(ref, name).reshape(-1))
+    bad = echoes.clone()
+    idx = torch.arange(0, n, 16, device=dev)
+    bad[3, idx[0::3]] = float("nan")
+    bad[5, idx[1::3]] = float("inf")  # (in the first echo it would be the k bound of --no_prior: infeasible, as scipy raises)
+    bad[0, idx[2::3]] = 20000.0
+    full = torch.ones_like(mask)
+    good = t2.fit_volume(vol, full, te, "gaussian_rician", table, prior=False, extras=True, strict=False)
+    got = t2.fit_volume(bad.reshape((8,) + shape), full, te, "gaussian_rician", table, prior=False, extras=True, strict=False)
+    st = got.status.reshape(-1)
+    assert bool((st[idx[0::3]] == _abi.ST_NONFINITE).all()) and bool((st[idx[1::3]] == _abi.ST_NONFINITE).all())
+    assert bool((st[idx[2::3]] == _abi.ST_INFEASIBLE).all()) and bool(torch.isnan(got.t2.reshape(-1)[idx[2::3]]).all())
+    assert bool((got.nit.reshape(-1)[idx] == 0).all())
+    keep = torch.ones(n, dtype=torch.bool, device=dev)
+    keep[idx] = False
+    for name in ("t2", "k", "sigma", "res", "nit", "status"):
+        assert _bitwise_equal(getattr(got, name).reshape(-1)[keep], getattr(good, name).reshape(-1)[keep]), name
+
+
 def test_config4_whole_uterus_slabs_equal_whole_volume(t2):
     """BASELINE.json config 4: 512 x 512 x 360 x 8 TE (94.4 M voxels, 3 GB of samples), the volume that is cut over
     eight GPUs.  One GPU holds it whole, so the partition can be checked at full size without the other seven: the fit
