@@ -318,6 +318,12 @@ template <int MODEL, int NTE = 0> struct LbfgsbLane {
   static constexpr int kWavesPerSimd = 1;
   // one-wave workgroups, two waves on a SIMD: the Rician lane (i0e) needs more than the 256 registers that allows
   static constexpr bool kWaveWgOk = MODEL != T2FIT_MODEL_RICIAN;
+#ifndef T2_WAVE_HINT_2PAR
+#define T2_WAVE_HINT_2PAR 2
+#endif
+  // (two parameters: 240 B of pairs per lane would let ten waves share a CU, but three waves per SIMD means 168
+  // registers, 29-45 of the lane's spill to scratch, and 7.28 ms become 7.75: profiles/r02_exp50_2par_three_waves.txt)
+  static constexpr int kWaveWgHint = MODEL == T2FIT_MODEL_GAUSSIAN ? T2_WAVE_HINT_2PAR : kWaveHint;
   static constexpr int kRefillMin = 8;   // measured on MI355X: 1 -> 28.1 ms, 8 -> 26.8 ms, 16 -> 27.6 ms
   static constexpr bool kSplit = true;   // advance() = digest() + begin(): the kernel may batch begin() (T2FIT_PARK_MIN)
   __device__ static void init(Solver& s, const ObjCtx&, const double* x0, const double* lb, const double* ub,
@@ -333,6 +339,7 @@ template <typename T, int NPAR, int NTE = 0> struct LmLaneAdaptor {
   static constexpr int kNte = NTE;
   static constexpr int kHistDoubles = 0;
   static constexpr bool kWaveWgOk = false;
+  static constexpr int kWaveWgHint = 1;
   // float32: four waves per SIMD (128 registers); float64: what the 229 registers of the lane allow (two, LDS permitting)
   static constexpr int kWavesPerSimd = sizeof(T) == 4 ? 4 : 1;
   static constexpr int kRefillMin = 24;  // measured (f32, 3 parameters, MI355X): 8 -> 1.62 ms, 16 -> 1.42 ms, 24 -> 1.35 ms, 32 -> 1.35 ms
@@ -873,8 +880,9 @@ hipError_t launch_persistent(unsigned grid, size_t lds_samples, hipStream_t st, 
     // (echo-count specialisation), the voxel queue too.
     if (g_wave_wg) {
       // (T2FIT_WAVE_WG=2 / 3: the same register-queue code in workgroups of 256 / 128 lanes -- diagnostic builds only)
-      auto k64 = extras ? fit_persistent_kernel<A, kChunkSmall, false, kWaveHint, true, 64, true>
-                        : fit_persistent_kernel<A, kChunkSmall, false, kWaveHint, false, 64, true>;
+      constexpr int kHint = A::kWaveWgHint;  // waves per SIMD the register allocator is held to
+      auto k64 = extras ? fit_persistent_kernel<A, kChunkSmall, false, kHint, true, 64, true>
+                        : fit_persistent_kernel<A, kChunkSmall, false, kHint, false, 64, true>;
       unsigned wg = 64;
 #if defined(T2_WG_SHAPE_DIAG)
       if (g_wave_wg == 2) { k64 = fit_persistent_kernel<A, kChunkSmall, false, 1, false, 256, true>; wg = 256; }
@@ -883,7 +891,7 @@ hipError_t launch_persistent(unsigned grid, size_t lds_samples, hipStream_t st, 
       size_t lds64 = (size_t)A::kHistDoubles * wg * sizeof(double);
       // (LDS is handed out in 1280-byte pieces, 128 to a CU: measured with tools/diag/wave_placement_probe.hip, five
       // workgroups of 32000 bytes are resident together, of 32768 four)
-      unsigned per_cu = (unsigned)std::min<size_t>(512 / wg, 128 / ((lds64 + 1279) / 1280));
+      unsigned per_cu = (unsigned)std::min<size_t>(wg == 64 ? 4 * kHint : 512 / wg, 128 / ((lds64 + 1279) / 1280));
       if (g_waves_per_cu > 0 && (unsigned)g_waves_per_cu < per_cu) {  // A/B switch: pad the allocation so that no more fit
         per_cu = (unsigned)g_waves_per_cu;
         lds64 = (size_t)(128 / per_cu) * 1280;
