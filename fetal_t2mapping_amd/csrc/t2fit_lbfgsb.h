@@ -135,7 +135,13 @@ struct LsState {
   double ginit, gtest, gx, gy, finit, fx, fy, stx, sty, stmin, stmax, width, width1;
 };
 
-T2_HD double t2_max3(double a, double b, double c) { return t2_max(a, t2_max(b, c)); }
+// min / max / abs of this solver: one instruction each (v_max_f64 / v_min_f64, |x| as an operand modifier) instead of a
+// compare and two selects.  They differ from the generic a > b ? a : b only when an operand is NaN (the non-NaN one
+// is returned) or a zero's sign matters; neither occurs between two evaluations of a finite objective.
+T2_HD double lb_max(double a, double b) { return __builtin_fmax(a, b); }
+T2_HD double lb_min(double a, double b) { return __builtin_fmin(a, b); }
+T2_HD double lb_abs(double a) { return __builtin_fabs(a); }
+T2_HD double t2_max3(double a, double b, double c) { return lb_max(a, lb_max(b, c)); }
 
 // One safeguarded cubic / secant step (MINPACK-2 dcstep).  The four cases of the original share
 // their cubic-interpolation arithmetic, so it is computed once on operands selected by case: the
@@ -150,16 +156,16 @@ T2_HD void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy, 
   const double sgnd = !(dx < 0.0 || dx > 0.0) ? (double)NAN : (dx < 0.0 ? -dp : dp);  // dp * (dx / |dx|): the factor is exactly +-1
   const bool c1 = fp > fx;                              // higher function value: minimum bracketed
   const bool c2 = !c1 && sgnd < 0.0;                    // derivatives of opposite sign: bracketed
-  const bool c3 = !c1 && !c2 && t2_abs(dp) < t2_abs(dx);  // derivative magnitude decreases
+  const bool c3 = !c1 && !c2 && lb_abs(dp) < lb_abs(dx);  // derivative magnitude decreases
   const bool c4 = !c1 && !c2 && !c3;                    // derivative does not decrease
   // cubic through (sta, fa, da) and (stp, fp, dp): a = y in case 4, a = x otherwise
   const double sta = c4 ? sty : stx, fa = c4 ? fy : fx, da = c4 ? dy : dx;
   const double theta = t2_fdiv(3.0 * (fa - fp), stp - sta) + da + dp;
-  const double s = t2_max3(t2_abs(theta), t2_abs(da), t2_abs(dp));
+  const double s = t2_max3(lb_abs(theta), lb_abs(da), lb_abs(dp));
   const double rs = t2_rcp_for_div(s);  // three quotients by s share its reciprocal
   const double ts = t2_div_by_rcp(theta, s, rs);
   double arg = ts * ts - t2_div_by_rcp(da, s, rs) * t2_div_by_rcp(dp, s, rs);
-  arg = c3 ? t2_max(0.0, arg) : arg;
+  arg = c3 ? lb_max(0.0, arg) : arg;
   double gamma = s * t2_sqrt_core(arg);
   const bool flip = c1 ? stp < stx : (c4 ? stp > sty : stp > stx);
   gamma = flip ? -gamma : gamma;
@@ -178,12 +184,12 @@ T2_HD void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy, 
   const double quad = c1 ? qq * 0.5 : qq;
   const double stpq = c1 ? stx + quad * (stp - stx) : stp + quad * (stx - stp);
   // the step taken
-  const double dc = t2_abs(stpc - stp), dq = t2_abs(stpq - stp);
-  const double f1 = t2_abs(stpc - stx) < t2_abs(stpq - stx) ? stpc : stpc + (stpq - stpc) * 0.5;
+  const double dc = lb_abs(stpc - stp), dq = lb_abs(stpq - stp);
+  const double f1 = lb_abs(stpc - stx) < lb_abs(stpq - stx) ? stpc : stpc + (stpq - stpc) * 0.5;
   const double farther = dc > dq ? stpc : stpq, nearer = dc < dq ? stpc : stpq;
   const double lim = stp + 0.66 * (sty - stp);
-  const double f3b = stp > stx ? t2_min(lim, nearer) : t2_max(lim, nearer);
-  const double f3u = t2_max(stpmin, t2_min(stpmax, farther));
+  const double f3b = stp > stx ? lb_min(lim, nearer) : lb_max(lim, nearer);
+  const double f3u = lb_max(stpmin, lb_min(stpmax, farther));
   const double f4 = brackt ? stpc : far_end;
   const double stpf = c1 ? f1 : (c2 ? farther : (c3 ? (brackt ? f3b : f3u) : f4));
   brackt = brackt || c1 || c2;
@@ -227,7 +233,7 @@ T2_HD int dcsrch_tests(double f, double g, double stp, double gtol, double xtol,
   if (s.brackt && s.stmax - s.stmin <= xtol * s.stmax) task = LS_WARN;  // xtol test satisfied
   if (stp == stpmax && f <= ftest && g <= s.gtest) task = LS_WARN;      // stp = stpmax
   if (stp == stpmin && (f > ftest || g >= s.gtest)) task = LS_WARN;     // stp = stpmin
-  if (f <= ftest && t2_abs(g) <= gtol * (-s.ginit)) task = LS_CONV;
+  if (f <= ftest && lb_abs(g) <= gtol * (-s.ginit)) task = LS_CONV;
   s.task = task;
   return task;
 }
@@ -246,17 +252,17 @@ T2_HD void dcsrch_update(double f, double g, double& stp, double xtol, double st
   s.fy = modified ? fym + s.sty * gt : fym;
   s.gx = modified ? gxm + gt : gxm;
   s.gy = modified ? gym + gt : gym;
-  const double span = t2_abs(s.sty - s.stx);
+  const double span = lb_abs(s.sty - s.stx);
   const double mid = s.stx + p5 * (s.sty - s.stx);
   stp = (s.brackt && span >= p66 * s.width1) ? mid : stp;
   s.width1 = s.brackt ? s.width : s.width1;
   s.width = s.brackt ? span : s.width;
-  const double lo_b = t2_min(s.stx, s.sty), hi_b = t2_max(s.stx, s.sty);
+  const double lo_b = lb_min(s.stx, s.sty), hi_b = lb_max(s.stx, s.sty);
   const double lo_u = stp + xtrapl * (stp - s.stx), hi_u = stp + xtrapu * (stp - s.stx);
   s.stmin = s.brackt ? lo_b : lo_u;
   s.stmax = s.brackt ? hi_b : hi_u;
-  stp = t2_max(stp, stpmin);
-  stp = t2_min(stp, stpmax);
+  stp = lb_max(stp, stpmin);
+  stp = lb_min(stp, stpmax);
   const bool stuck = s.brackt && ((stp <= s.stmin || stp >= s.stmax) || (s.stmax - s.stmin <= xtol * s.stmax));
   stp = stuck ? s.stx : stp;
   s.task = LS_FG;
@@ -348,11 +354,11 @@ struct Lbfgsb {
     for (int i = 0; i < N; ++i) {
       double h = P.fd_step;
       if ((x[i] + h) - x[i] == 0.0)  // step lost to rounding: scipy falls back to sqrt(eps) relative
-        h = 1.4901161193847656e-08 * (x[i] >= 0 ? 1.0 : -1.0) * t2_max(1.0, t2_abs(x[i]));
+        h = 1.4901161193847656e-08 * (x[i] >= 0 ? 1.0 : -1.0) * lb_max(1.0, lb_abs(x[i]));
       const double lower = x[i] - lb[i], upper = ub[i] - x[i];
       const double xs = x[i] + h;
       const bool violated = xs < lb[i] || xs > ub[i];
-      const bool fitting = t2_abs(h) <= t2_max(lower, upper);
+      const bool fitting = lb_abs(h) <= lb_max(lower, upper);
       if (violated && fitting) h = -h;
       if (!fitting) h = upper >= lower ? upper : -lower;
       x1[i] = x[i] + h;
@@ -452,9 +458,9 @@ struct Lbfgsb {
     T2_UNROLL
     for (int i = 0; i < N; ++i) {
       double gi = g[i];
-      if (gi < 0.0) gi = t2_max(x[i] - ub[i], gi);
-      else gi = t2_min(x[i] - lb[i], gi);
-      nrm = t2_max(nrm, t2_abs(gi));
+      if (gi < 0.0) gi = lb_max(x[i] - ub[i], gi);
+      else gi = lb_min(x[i] - lb[i], gi);
+      nrm = lb_max(nrm, lb_abs(gi));
     }
     return nrm;
   }
@@ -474,11 +480,11 @@ struct Lbfgsb {
     for (int i = 1; i < N; ++i) sv[i] = hratio(q, i - 1);
   }
   T2_HD void store_s(int q, const double* sv) {
-    double big = t2_abs(sv[0]);
+    double big = lb_abs(sv[0]);
     T2_UNROLL
-    for (int i = 1; i < N; ++i) big = t2_max(big, t2_abs(sv[i]));
+    for (int i = 1; i < N; ++i) big = lb_max(big, lb_abs(sv[i]));
     const double least = big * 0x1p-400;  // s is not zero here (y's > 0)
-    const double p0 = t2_abs(sv[0]) < least ? (sv[0] < 0.0 ? -least : least) : sv[0];
+    const double p0 = lb_abs(sv[0]) < least ? (sv[0] < 0.0 ? -least : least) : sv[0];
     const double r = t2_rcp_for_div(p0);
     T2_UNROLL
     for (int i = 1; i < N; ++i) hratio(q, i - 1) = t2_div_by_rcp(sv[i], p0, r);
@@ -564,7 +570,7 @@ struct Lbfgsb {
       const double tl = x[i] - lb[i], tu = ub[i] - x[i];
       {
         const bool xlower = tl <= 0.0, xupper = tu <= 0.0;
-        const int iw = xlower ? (neggi <= 0.0 ? 1 : 0) : (xupper ? (neggi >= 0.0 ? 2 : 0) : (t2_abs(neggi) <= 0.0 ? -3 : 0));
+        const int iw = xlower ? (neggi <= 0.0 ? 1 : 0) : (xupper ? (neggi >= 0.0 ? 2 : 0) : (lb_abs(neggi) <= 0.0 ? -3 : 0));
         iwhere[i] = (live && iwhere[i] != 3) ? iw : iwhere[i];
       }
       d[i] = 0.0; tbk[i] = 0.0; zfix[i] = 0.0; hasbk[i] = false;
@@ -572,7 +578,7 @@ struct Lbfgsb {
         d[i] = neggi;
         f1 = fma(-neggi, neggi, f1);
         if (neggi != 0.0) {  // one division on the selected numerator instead of one per branch
-          tbk[i] = t2_fdiv(neggi < 0.0 ? tl : tu, t2_abs(neggi));
+          tbk[i] = t2_fdiv(neggi < 0.0 ? tl : tu, lb_abs(neggi));
           hasbk[i] = true;
           ++nbreak;
         }
@@ -646,12 +652,12 @@ struct Lbfgsb {
         for (int j = 0; j < N; ++j) bz = fma(B[i][j], z[j], bz);
         f1 = fma(d[i], g[i] + bz, f1);
       }
-      f2 = t2_max(epsmch * f2_org, dBd(d));
+      f2 = lb_max(epsmch * f2_org, dBd(d));
       if (nleft > 0) dtm = t2_fdiv(-f1, f2);
       else { f1 = 0.0; f2 = 0.0; dtm = 0.0; }  // all remaining variables are box-bounded
     }
     const bool commit = start && !all_fixed;
-    dtm = t2_max(dtm, 0.0);
+    dtm = lb_max(dtm, 0.0);
     tsum += dtm;
     T2_UNROLL
     for (int i = 0; i < N; ++i) xcp[i] = commit ? fma(tsum, d[i], xcp[i]) : xcp[i];
@@ -704,8 +710,8 @@ struct Lbfgsb {
     for (int i = 0; i < N; ++i) {
       xp[i] = z[i];
       if (fr[i]) {
-        const double xk = t2_max(lb[i], z[i] + du[i]);
-        z[i] = t2_min(ub[i], xk);
+        const double xk = lb_max(lb[i], z[i] + du[i]);
+        z[i] = lb_min(ub[i], xk);
         if (z[i] == lb[i] || z[i] == ub[i]) projected = true;
       }
     }
@@ -819,7 +825,7 @@ struct Lbfgsb {
     const double tol = P.lbfgsb_tol;  // factr * epsmch = (ftol / epsmch) * epsmch, formed on the host
     const int nit1 = nit + 1;
     const bool out_of_budget = nit1 >= P.maxiter || nfev > P.maxfun;  // scipy: STOP, success False
-    const bool converged = sb <= P.gtol || (!was_first && (fold - f) <= tol * t2_max3(t2_abs(fold), t2_abs(f), 1.0));
+    const bool converged = sb <= P.gtol || (!was_first && (fold - f) <= tol * t2_max3(lb_abs(fold), lb_abs(f), 1.0));
     double rn[N], dn[N], rr = 0.0;
     T2_UNROLL
     for (int i = 0; i < N; ++i) { rn[i] = g[i] - r[i]; rr += rn[i] * rn[i]; }
