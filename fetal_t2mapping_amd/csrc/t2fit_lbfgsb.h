@@ -315,9 +315,9 @@ struct Lbfgsb {
   double z[N], d[N], t[N], r[N];    // line-search frame: target, direction, x_old, g_old
   double fold, gd, gdold, stp, stpmx, sbgnrm, theta;
   LsState ls;
-  // correction pairs live outside the lane's registers: a ring of M slots of (s, y), element e of
-  // slot q at hist[(q*2N + e) * hstride].  In the kernel that is LDS (one column per lane, 480 B per
-  // lane for n = 3), which is what keeps the solver state within the VGPR budget.
+  // correction pairs live outside the lane's registers: a ring of M slots of PAIR doubles (the ratios of s, then
+  // y / sqrt(y's): see store_s), element e of slot q at hist[(q*PAIR + e) * hstride].  In the kernel that is LDS (one
+  // column per lane, 400 B per lane for n = 3), which is what keeps the solver state within the VGPR budget.
   double* hist;
   int hstride, head;
   int iwhere[N];
