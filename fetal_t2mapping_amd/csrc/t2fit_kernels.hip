@@ -356,7 +356,8 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
                                                unsigned long long* next_chunk, int refill_min, int park_min) {
   extern __shared__ float lds[];
   constexpr int NP = A::NP;
-  // kWg == 64: one wave per workgroup (see launch_persistent: more waves per CU than four), queue in a register
+  // kRegs: samples and voxel queue in registers, LDS for the correction pairs only -- the form launched as one-wave
+  // workgroups (kWg == 64; see launch_persistent: six or eight waves per CU instead of four)
   constexpr bool kWaveWg = kRegs;
   static_assert(kRegs ? (kChunk == 64 && A::kNte > 0 && A::kNte <= 8) : kWg == kBlock,
                 "workgroup of 256 lanes, or waves taking 64-voxel chunks with the samples in registers");
@@ -364,7 +365,7 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* col = lds + threadIdx.x;
   // LDS, kWg == 256: [n_te][257] float sample columns | [kHistDoubles][256] double solver history | 4 queues
-  //      kWg == 64:  [kHistDoubles][64] double solver history, nothing else (samples and queue are in registers)
+  //      kRegs:      [kHistDoubles][kWg] double solver history, nothing else (samples and queue are in registers)
   double* hist = reinterpret_cast<double*>(lds + (kWaveWg ? 0 : ((P.n_te * kStride + 1) & ~1))) + threadIdx.x;
   uint32_t* queue = reinterpret_cast<uint32_t*>(hist - threadIdx.x + A::kHistDoubles * kWg) + wave * kQueueCap;
   uint32_t qv = 0;  // kWaveWg: lane r holds the r-th waiting voxel of the chunk last taken
