@@ -111,13 +111,18 @@ __device__ __forceinline__ void stage_echoes(float* lds, const float* __restrict
 
 // kExtras = false: the caller asked for the reference's four maps only; the optional outputs are not even tested
 // for (their pointers would otherwise live in scalar registers across the whole persistent loop)
-template <bool kExtras = true>
+// kEpilogueFollows: the persistent fits are followed by residuals_kernel, which writes res / r2 / se of every voxel
+// (zeros outside the mask): storing those zeros here as well would write the same lines twice
+template <bool kExtras = true, bool kEpilogueFollows = false>
 __device__ __forceinline__ void store_masked(const DevMaps& m, int64_t v) {
   // zeros outside the mask (run_t2mapping.py:415-418)
-  m.t2[v] = 0.0f; m.k[v] = 0.0f; m.sigma[v] = 0.0f; m.res[v] = 0.0f;
+  m.t2[v] = 0.0f; m.k[v] = 0.0f; m.sigma[v] = 0.0f;
+  if constexpr (!kEpilogueFollows) m.res[v] = 0.0f;
   if constexpr (!kExtras) return;
-  if (m.r2) m.r2[v] = 0.0f;
-  if (m.se) m.se[v] = 0.0f;
+  if constexpr (!kEpilogueFollows) {
+    if (m.r2) m.r2[v] = 0.0f;
+    if (m.se) m.se[v] = 0.0f;
+  }
   if (m.fun) m.fun[v] = 0.0f;
   if (m.nit) m.nit[v] = 0;
   if (m.status) m.status[v] = T2FIT_ST_MASKED;
@@ -463,7 +468,7 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
             // a full permutation: active lanes to the front in order, the others behind them
             const int dst = act ? __popcll(b & lt_mask) : q_count + __popcll(~b & lt_mask);
             qv = (uint32_t)__builtin_amdgcn_ds_permute(dst << 2, (int)(uint32_t)vv);
-            if (vv < n_vox && !act) store_masked<kExtras>(m, vv);
+            if (vv < n_vox && !act) store_masked<kExtras, true>(m, vv);
             if (q_count == 0) continue;
           }
           const int rank = __popcll(want & lt_mask);
@@ -511,7 +516,7 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
 #pragma unroll
         for (int q = 0; q < kChunk / 64; ++q) {
           const int64_t vv = base + q * 64 + lane;
-          if (vv < n_vox && !act[q]) store_masked<kExtras>(m, vv);
+          if (vv < n_vox && !act[q]) store_masked<kExtras, true>(m, vv);
         }
       }
       if (!busy) {

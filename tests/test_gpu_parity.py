@@ -898,6 +898,47 @@ def test_large_volume_kernels_equal_the_small_volume_kernel(t2, fit, n_te, prior
         del whole
 
 
+@pytest.mark.parametrize("fit,precision,n_te", [("gaussian_rician", "f32", 8), ("gaussian_rician", "f64", 8), ("gaussian", "f32", 6),
+                                                ("gaussian_rician", "f64", 5)], ids=lambda v: str(v))
+def test_lm_large_volume_equals_small_pieces(t2, fit, precision, n_te):
+    """The LM kernels at size: small volumes are taken in 64-voxel chunks, large ones in 256-voxel chunks (and the
+    float64 lane has the echo count as a constant there).  A large ragged volume, with and without a mask and with
+    voxels that end at once (NaN samples), must equal its fit in pieces (other chunk boundaries, other queues) bit for
+    bit -- every voxel written, zeros outside the mask -- and two runs of the same volume must agree."""
+    import torch
+
+    from fetal_t2mapping_amd import synth
+
+    dev = torch.device("cuda", 0)
+    shape = (40, 256, 256)
+    echoes, mask, te = synth.brain_volume_torch(shape, n_te, synth.SEED_BASE + 13, dev)
+    n = shape[0] * shape[1] * shape[2] - 101
+    echoes = echoes[:, :n].contiguous()
+    echoes[2, torch.arange(7, n, 97, device=dev)] = float("nan")
+    table = t2.fit_table(fit, True)
+    for msk in (mask[:n].contiguous(), None):
+        whole = t2.fit_volume(echoes.reshape(n_te, 1, 1, n), msk, te, fit, table, solver="lm", precision=precision, extras=True)
+        torch.cuda.synchronize()
+        # float32 runs the same lane in both kernels; the float64 large-volume kernel has the echo count as a constant
+        # (other contractions, last-bit differences against the generic lane): cut it into pieces that are still large
+        piece = 300000 if precision == "f32" else 1310001
+        for lo in range(0, n, piece):
+            hi = min(n, lo + piece)
+            part = t2.fit_volume(echoes[:, lo:hi].contiguous().reshape(n_te, 1, 1, hi - lo),
+                                 None if msk is None else msk[lo:hi].contiguous(), te, fit, table, solver="lm",
+                                 precision=precision, extras=True)
+            for name in ("t2", "k", "sigma", "res", "nit", "status"):
+                assert _bitwise_equal(getattr(whole, name).reshape(-1)[lo:hi], getattr(part, name).reshape(-1)), (name, lo)
+        if msk is not None:
+            out = ~msk.bool()
+            assert all(bool((getattr(whole, k).reshape(-1)[out] == 0).all()) for k in ("t2", "k", "sigma", "res"))
+        del whole
+    plain = t2.fit_volume(echoes.reshape(n_te, 1, 1, n), mask[:n].contiguous(), te, fit, table, solver="lm", precision=precision)
+    again = t2.fit_volume(echoes.reshape(n_te, 1, 1, n), mask[:n].contiguous(), te, fit, table, solver="lm", precision=precision)
+    for name in ("t2", "k", "sigma", "res"):
+        assert _bitwise_equal(getattr(plain, name), getattr(again, name))
+
+
 def test_large_volume_kernels_on_empty_masks_and_bad_samples(t2):
     """The large-volume kernels' chunk queue on inputs that starve it: a mask that is zero everywhere (every chunk is
     empty: all maps zero, every status MASKED), a mask with a single voxel at the very end, and a volume in which every
