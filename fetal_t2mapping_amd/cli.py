@@ -100,12 +100,12 @@ def _read_subject(sitk, recon_paths, mask_paths, label_path):
 
 # ---- metadata / paths --------------------------------------------------------------------------
 def mk_bids_dir(bids_dir, *dirs):
-    """utils/dcm_utils.py:189-195."""
+    """utils/dcm_utils.py:189-195 (there: `if not exists: mkdir`; with --gpus N several ranks create the shared
+    parents of their subjects' directories at the same moment, so an existing directory is not an error here)."""
     path = bids_dir
     for d in dirs:
         path = os.path.join(path, d)
-        if not os.path.exists(path):
-            os.mkdir(path)
+        os.makedirs(path, exist_ok=True)
 
 
 def get_img_path(bids_path, acq, type: str = "anat"):
