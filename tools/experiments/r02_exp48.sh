@@ -6,4 +6,4 @@ python bench.py --cpu-seconds 0 --no-also --pipeline on 2>/dev/null | show "256^
 python bench.py --cpu-seconds 0 --no-also --shape 32 256 256 2>/dev/null | show "32 slices default"
 python bench.py --cpu-seconds 0 --no-also --shape 32 256 256 --pipeline on 2>/dev/null | show "32 slices pipelined"
 } 2>&1 | tee gpurun_out/r02_exp48_bench_pipeline.txt
-timeout -k 10 800 python -m pytest tests -q -m gpu -x -k "two_ranks or abi or sharded" 2>&1 | tail -3
+
