@@ -871,7 +871,9 @@ FitKernel pick_kernel(const t2fit_config& c) {
 
 // kLargeOnly: instantiate the two large-volume kernels only (the echo-count specialisations; small volumes and
 // traced voxel batches use the generic lane, where compile time buys nothing)
-template <class A, bool kLargeOnly = false>
+// kWaveOnly: instantiate the one-wave-workgroup kernels of A only (the less common echo counts: compile time); where
+// they do not apply (T2FIT_WAVE_WG=0, diagnostic builds) hipErrorNotSupported tells the caller to use the generic lane
+template <class A, bool kLargeOnly = false, bool kWaveOnly = false>
 hipError_t launch_persistent(unsigned grid, size_t lds_samples, hipStream_t st, const LaneParams& P,
                              const float* echoes, int layout, const uint8_t* mask, int64_t n_vox, const DevMaps& dm,
                              unsigned long long* counter) {
@@ -915,6 +917,9 @@ hipError_t launch_persistent(unsigned grid, size_t lds_samples, hipStream_t st, 
     }
   }
 #endif
+  if constexpr (kWaveOnly) {
+    return hipErrorNotSupported;
+  } else {
   auto kern = extras ? fit_persistent_kernel<A, kChunkLarge, false, W, true>
                      : fit_persistent_kernel<A, kChunkLarge, false, W, false>;
   if constexpr (!kLargeOnly) {
@@ -935,6 +940,7 @@ hipError_t launch_persistent(unsigned grid, size_t lds_samples, hipStream_t st, 
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox, dm, counter,
                      g_refill_min > 0 ? g_refill_min : A::kRefillMin, g_park_min);
   return hipGetLastError();
+  }
 }
 
 // reference-trajectory lane for `model`, specialised for the common echo-train lengths on large volumes
@@ -946,6 +952,16 @@ hipError_t launch_lbfgsb(int n_te, bool large, unsigned grid, size_t lds_samples
     if (n_te == 8) return launch_persistent<LbfgsbLane<MODEL, 8>, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);
     if (n_te == 6) return launch_persistent<LbfgsbLane<MODEL, 6>, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);
     if (n_te == 3) return launch_persistent<LbfgsbLane<MODEL, 3>, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);
+    // 7 / 5 / 4 echoes: the one-wave-workgroup kernels only (16.2 -> 12.6 ms at 5 echoes against the generic lane)
+    if constexpr (MODEL != T2FIT_MODEL_RICIAN) {
+      hipError_t e = hipErrorNotSupported;
+      if (g_wave_wg == 1) {
+        if (n_te == 7) e = launch_persistent<LbfgsbLane<MODEL, 7>, true, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);
+        if (n_te == 5) e = launch_persistent<LbfgsbLane<MODEL, 5>, true, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);
+        if (n_te == 4) e = launch_persistent<LbfgsbLane<MODEL, 4>, true, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);
+      }
+      if (e != hipErrorNotSupported) return e;
+    }
   }
   return launch_persistent<LbfgsbLane<MODEL>>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);
 }

@@ -857,12 +857,14 @@ def test_config2_and_config3_adult_brain_at_size(t2):
 
 @pytest.mark.parametrize("fit,n_te,prior,norm", [("gaussian_rician", 8, True, False), ("gaussian_rician", 6, False, False),
                                                  ("gaussian_rician", 3, True, True), ("gaussian", 6, True, False),
-                                                 ("gaussian", 8, False, True), ("rician", 6, True, False)],
+                                                 ("gaussian", 8, False, True), ("rician", 6, True, False),
+                                                 ("gaussian_rician", 7, True, False), ("gaussian_rician", 5, False, False),
+                                                 ("gaussian", 4, True, False), ("gaussian_rician", 9, True, False)],
                          ids=lambda v: str(v))
 def test_large_volume_kernels_equal_the_small_volume_kernel(t2, fit, n_te, prior, norm):
-    """Volumes above 2^20 voxels with 8 / 6 / 3 echoes run the echo-count specialised kernels (one-wave workgroups with
-    samples and voxel queue in registers for the 2- and 3-parameter Gaussian objectives: five / eight waves per CU),
-    everything else the generic 256-lane kernel.  Same voxels, cut into pieces small enough for the generic kernel:
+    """Volumes above 2^20 voxels with 3 to 8 echoes run the echo-count specialised kernels (one-wave workgroups with
+    samples and voxel queue in registers for the 2- and 3-parameter Gaussian objectives: six / eight waves per CU),
+    everything else (other echo counts, the Rician-likelihood objective, small volumes) the generic 256-lane kernel.  Same voxels, cut into pieces small enough for the generic kernel:
     the maps must agree bit for bit -- with a ragged voxel count (not a multiple of 64), without a mask, with the
     normalised signal, under --no_prior."""
     import torch

@@ -1,5 +1,5 @@
 """Randomised cross-check of the large-volume kernels (one-wave workgroups, samples in registers) against the generic
-small-volume kernel: random sizes just above 2^20 voxels, ragged ends, mask fills from 0.5 % to 100 %, 3 / 6 / 8 echoes,
+small-volume kernel: random sizes just above 2^20 voxels, ragged ends, mask fills from 0.5 % to 100 %, 3 to 8 echoes,
 both Gaussian objectives, prior / no prior, both layouts.  Every map must be bit-identical.  python tools/soak_kernel_variants.py [n_cases]"""
 import os
 import sys
@@ -17,7 +17,7 @@ rng = np.random.default_rng(2026)
 dev = torch.device("cuda", 0)
 bad = 0
 for case in range(n_cases):
-    n_te = int(rng.choice([3, 6, 8]))
+    n_te = int(rng.choice([3, 4, 5, 6, 7, 8]))
     fit = str(rng.choice(["gaussian", "gaussian_rician"]))
     prior = bool(rng.integers(0, 2))
     layout = str(rng.choice(["te_major", "voxel_major"]))
