@@ -304,7 +304,12 @@ __global__ __launch_bounds__(kBlock) void loglin_volume_kernel(const LaneParams 
 // (divergent, cheap); the wave leaves when a __ballot shows no lane has work and the queue is dry.
 constexpr int kChunkLarge = 256;  // voxels a wave takes from the global queue at a time
 constexpr int kChunkSmall = 64;   // small volumes (phantoms): more, smaller chunks so that every wave gets work
-constexpr int64_t kSmallVolume = 1 << 20;
+constexpr int64_t kSmallVolumeDefault = 1 << 20;
+int64_t kSmallVolume = kSmallVolumeDefault;  // T2FIT_SMALL_VOLUME overrides (A/B runs): at or below, the generic small-chunk kernels
+// T2FIT_TAKE: 64-voxel chunks per counter increment in the one-wave-workgroup kernels.  Measured (256^3 x 8 TE and its
+// 1/2, 1/4, 1/8 shares, profiles/r02_exp58_mid_size.txt): 2 is best throughout -- 4 lengthens the drain of a launch
+// (2.55 against 2.32 ms on a 1/8 share), 1 costs a little on whole volumes (13.73 against 13.55 ms)
+int g_take = 0;
 constexpr int kQueueCap = 64 + kChunkLarge;
 constexpr int kDiagBlocks = 11, kDiagWords = 3 * kDiagBlocks;  // -DT2_PHASE_STAMPS: (cycles, lanes, entries) per block
 #if defined(T2_WG_SHAPE_DIAG)
@@ -358,7 +363,7 @@ template <typename T, int NPAR, int NTE = 0> struct LmLaneAdaptor {
 template <class A, int kChunk, bool kTrace, bool kExtras, int kWg = kBlock, bool kRegs = false>
 __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float* __restrict__ echoes, int layout,
                                                const uint8_t* __restrict__ mask, int64_t n_vox, const DevMaps& m,
-                                               unsigned long long* next_chunk, int refill_min, int park_min) {
+                                               unsigned long long* next_chunk, int refill_min, int park_min, int take) {
   extern __shared__ float lds[];
   constexpr int NP = A::NP;
   // kRegs: samples and voxel queue in registers, LDS for the correction pairs only -- the form launched as one-wave
@@ -408,7 +413,8 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
   int pend = 0;
   // kWaveWg: the chunk queue is read two steps ahead, so that taking a chunk never waits for memory -- chunk A has
   // its base and its mask bytes (loaded when the chunk before it was taken), chunk B its counter value (lane 0)
-  constexpr int kTake = 4;  // one counter increment hands a wave kTake 64-voxel chunks in a row (fewer same-address atomics)
+  // one counter increment hands a wave `take` 64-voxel chunks in a row (launch_persistent: 2)
+  const int kTake = take;
   int64_t base_a = 0;
   int sub_a = 0;
   uint32_t idx_b = 0;
@@ -669,8 +675,8 @@ __global__ __launch_bounds__(kWg, kWavesPerSimd) void fit_persistent_kernel(cons
                                                                     const float* __restrict__ echoes, int layout,
                                                                     const uint8_t* __restrict__ mask, int64_t n_vox,
                                                                     DevMaps m, unsigned long long* next_chunk, int refill_min,
-                                                                    int park_min) {
-  persistent_fit<A, kChunk, kTrace, kExtras, kWg, kRegs>(P, echoes, layout, mask, n_vox, m, next_chunk, refill_min, park_min);
+                                                                    int park_min, int take) {
+  persistent_fit<A, kChunk, kTrace, kExtras, kWg, kRegs>(P, echoes, layout, mask, n_vox, m, next_chunk, refill_min, park_min, take);
 }
 
 // Residual map (utils/t2map_utils.py:62-89) and optional R^2 from float32 maps already on the device.
@@ -912,7 +918,8 @@ hipError_t launch_persistent(unsigned grid, size_t lds_samples, hipStream_t st, 
       if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
       grid = std::min<unsigned>(grid, (unsigned)cus);  // every wave that fits is resident; more would only start to leave
       hipLaunchKernelGGL(k64, dim3(grid * per_cu), dim3(wg), lds64, st, P, echoes, layout, mask, n_vox, dm, counter,
-                         g_refill_min > 0 ? g_refill_min : A::kRefillMin, g_park_min);
+                         g_refill_min > 0 ? g_refill_min : A::kRefillMin, g_park_min,
+                         g_take > 0 ? g_take : 2);
       return hipGetLastError();
     }
   }
@@ -938,7 +945,7 @@ hipError_t launch_persistent(unsigned grid, size_t lds_samples, hipStream_t st, 
                                      (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox, dm, counter,
-                     g_refill_min > 0 ? g_refill_min : A::kRefillMin, g_park_min);
+                     g_refill_min > 0 ? g_refill_min : A::kRefillMin, g_park_min, 1);
   return hipGetLastError();
   }
 }
@@ -993,6 +1000,8 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
     if (const char* e = std::getenv("T2FIT_REFILL_MIN")) g_refill_min = std::min(64, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("T2FIT_RESERVE_CUS"); e && !g_reserve_set) g_reserve_cus = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("T2FIT_NTE_SPECIAL")) g_nte_special = std::atoi(e) != 0;
+    if (const char* e = std::getenv("T2FIT_TAKE")) g_take = std::max(0, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("T2FIT_SMALL_VOLUME")) kSmallVolume = std::max<int64_t>(0, std::atoll(e));
     if (const char* e = std::getenv("T2FIT_PARK_MIN")) g_park_min = std::min(64, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("T2FIT_WAVE_WG")) g_wave_wg = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("T2FIT_WAVES_PER_CU")) g_waves_per_cu = std::max(0, std::atoi(e));
