@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_TE = 32
 
 OK, E_INVALID, E_HIP, E_BOUNDS = 0, -1, -2, -3
@@ -26,7 +26,7 @@ class T2FitConfig(C.Structure):
     _fields_ = [
         ("abi_version", C.c_int32), ("model", C.c_int32), ("solver", C.c_int32), ("precision", C.c_int32),
         ("n_te", C.c_int32), ("no_prior", C.c_int32), ("norm", C.c_int32), ("maxls", C.c_int32),
-        ("maxiter", C.c_int32), ("maxfun", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32),
+        ("maxiter", C.c_int32), ("maxfun", C.c_int32), ("numpy_legacy", C.c_int32), ("reserved1", C.c_int32),
         ("te_ms", C.c_double * MAX_TE),
         ("x0", C.c_double * 3), ("lb", C.c_double * 3), ("ub", C.c_double * 3),
         ("ftol", C.c_double), ("gtol", C.c_double), ("fd_step", C.c_double), ("lm_xtol", C.c_double),

@@ -82,6 +82,7 @@ inline int config_check(const t2fit_config* c, const char** why) {
       *why = "te_ms must be positive and ascending";
       return T2FIT_E_INVALID;
     }
+  if (c->numpy_legacy != 0 && c->numpy_legacy != 1) { *why = "numpy_legacy must be 0 or 1"; return T2FIT_E_INVALID; }
   if (c->maxls <= 0) { *why = "maxls must be positive"; return T2FIT_E_INVALID; }  // scipy raises too
   const int np = c->model == T2FIT_MODEL_GAUSSIAN ? 2 : 3;
   for (int j = 0; j < np; ++j) {

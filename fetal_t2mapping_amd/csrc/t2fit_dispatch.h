@@ -17,7 +17,7 @@ inline LaneParams make_lane_params(const t2fit_config& c) {
   LaneParams P;
   P.model = c.model; P.solver = c.solver; P.precision = c.precision; P.n_te = c.n_te;
   P.no_prior = c.no_prior; P.norm = c.norm; P.maxls = c.maxls; P.maxiter = c.maxiter;
-  P.maxfun = c.maxfun; P.pad0 = 0;
+  P.maxfun = c.maxfun; P.numpy_legacy = c.numpy_legacy != 0;
   for (int i = 0; i < T2FIT_MAX_TE; ++i) {
     P.te[i] = i < c.n_te ? c.te_ms[i] : 0.0;
     P.te_f[i] = (float)P.te[i];

@@ -29,7 +29,7 @@ namespace t2fit {
 // kernel argument: it lives in the kernarg segment and uniform-index reads become scalar loads.
 struct LaneParams {
   int32_t model, solver, precision, n_te;
-  int32_t no_prior, norm, maxls, maxiter, maxfun, pad0;
+  int32_t no_prior, norm, maxls, maxiter, maxfun, numpy_legacy;
   double te[T2FIT_MAX_TE];
   float te_f[T2FIT_MAX_TE];
   double x0[3], lb[3], ub[3];
@@ -305,16 +305,23 @@ T2_HD double t2_div_by_rcp(double a, double b, double r) {
 // Mean signed residual from the float32 maps (utils/t2map_utils.py:62-89): float64 prediction
 // stored as float32, float32 residuals, numpy's pairwise float32 row sum, divided by nTE.
 // This is the arithmetic of numpy >= 2 (NEP 50: the np.float64 echo time promotes the prediction to float64), which
-// the fixtures were generated with; the reference's frozen numpy 1.26 would evaluate the prediction in float32
-// (about 1e-4 absolute difference: parity with that environment is unpinned, tests/golden/README.md).
+// the default fixtures were generated with.  Under the numpy 1.26 the reference freezes, value-based casting turns the
+// echo time into a float32 and the whole prediction is float32 (utils/t2map_utils.py:74-80; about 1e-4 absolute
+// difference): cfg.numpy_legacy selects that form (fixtures tests/golden/frozen_voxels_*.npz).
 T2_HD float residual_mean(const ObjCtx& c, float k32, float t232, float s32) {
   const int n = c.P->n_te;
   const bool gauss = c.P->model == T2FIT_MODEL_GAUSSIAN;
+  const bool legacy = c.P->numpy_legacy != 0;
   const double k = (double)k32, t2 = (double)t232;
   const double k2 = (double)(k32 * k32), s2 = (double)(s32 * s32);  // float32 squares, as numpy
   const double rt2 = 1.0 / t2;
   auto resid = [&](int i) {
     const double te = c.P->te[i];
+    if (legacy) {  // float32 throughout: k * exp(float32(-te) / t2), sqrt(k^2 * exp(float32(-2 te) / t2) + s^2)
+      const float pf = gauss ? k32 * expf((float)(-te) / t232)
+                             : sqrtf((k32 * k32) * expf((float)(-2.0 * te) / t232) + s32 * s32);
+      return c.sample(i) - pf;
+    }
     double pred;
     if (gauss) pred = k * t2_exp_res(t2_div_by_rcp(-te, t2, rt2), c.P->exp_c);
     else pred = t2_sqrt(k2 * t2_exp_res(t2_div_by_rcp(-2.0 * te, t2, rt2), c.P->exp_c) + s2);

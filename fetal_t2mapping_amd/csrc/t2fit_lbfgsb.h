@@ -69,9 +69,16 @@ namespace t2fit {
 // np.sum over a contiguous float64 vector: sequential for n < 8, otherwise eight interleaved
 // partial sums combined as a balanced tree plus a sequential tail (numpy pairwise_sum).
 template <int MODEL> struct ObjTerm;
+// np.log(signal) - np.log(sigma**2) of run_t2mapping.py:169: a float32 array minus a float64 scalar.  numpy >= 2
+// (NEP 50) promotes to float64; numpy < 2 -- the reference freezes 1.26.0, requirements_frozen.txt:103 -- casts the
+// scalar to float32 and subtracts in float32 (cfg.numpy_legacy).  With the forward-difference step of 1e-8 the
+// float32 form almost never sees sigma move: the two trajectories differ on most voxels.
+T2_HD double rician_log_term(float log_y, double log_s2, bool legacy) {
+  return legacy ? (double)(log_y - (float)log_s2) : (double)log_y - log_s2;
+}
 template <> struct ObjTerm<T2FIT_MODEL_GAUSSIAN> {
   double k, t2;
-  T2_HD void set(const double* x) { k = x[0]; t2 = x[1]; }
+  T2_HD void set(const ObjCtx&, const double* x) { k = x[0]; t2 = x[1]; }
   T2_HD double at(const ObjCtx& c, int i) const {
     const double r = (double)c.sample(i) - k * t2_exp_core(t2_fdiv(-c.P->te[i], t2));
     return r * r;
@@ -80,7 +87,7 @@ template <> struct ObjTerm<T2FIT_MODEL_GAUSSIAN> {
 };
 template <> struct ObjTerm<T2FIT_MODEL_GAUSSIAN_RICIAN> {
   double k2, t2, s2;
-  T2_HD void set(const double* x) { k2 = x[0] * x[0]; t2 = x[1]; s2 = x[2] * x[2]; }
+  T2_HD void set(const ObjCtx&, const double* x) { k2 = x[0] * x[0]; t2 = x[1]; s2 = x[2] * x[2]; }
   T2_HD double at(const ObjCtx& c, int i) const {
     const double r = (double)c.sample(i) - t2_sqrt_core(k2 * t2_exp_core(t2_fdiv(-2.0 * c.P->te[i], t2)) + s2);
     return r * r;
@@ -89,12 +96,16 @@ template <> struct ObjTerm<T2FIT_MODEL_GAUSSIAN_RICIAN> {
 };
 template <> struct ObjTerm<T2FIT_MODEL_RICIAN> {
   double k, t2, s2, ls2;
-  T2_HD void set(const double* x) { k = x[0]; t2 = x[1]; s2 = x[2] * x[2]; ls2 = t2_log(s2); }
+  bool legacy;
+  T2_HD void set(const ObjCtx& c, const double* x) {
+    k = x[0]; t2 = x[1]; s2 = x[2] * x[2]; ls2 = t2_log(s2);
+    legacy = c.P->numpy_legacy != 0;
+  }
   T2_HD double at(const ObjCtx& c, int i) const {
     const float yf = c.sample(i);
     const double m = k * t2_exp_core(t2_fdiv(-c.P->te[i], t2));
     const double xx = t2_fdiv(m * (double)yf, s2);
-    const double a = (double)logf(yf) - ls2;
+    const double a = rician_log_term(logf(yf), ls2, legacy);
     const double b = t2_fdiv((double)(yf * yf) + m * m, 2.0 * s2);
     const double d = (xx < 0 ? -xx : xx) + t2_log(t2_i0e(xx));
     return (a - b) + d;
@@ -105,7 +116,7 @@ template <> struct ObjTerm<T2FIT_MODEL_RICIAN> {
 template <int MODEL>
 T2_HD double objective_t(const ObjCtx& c, const double* x) {
   ObjTerm<MODEL> t;
-  t.set(x);
+  t.set(c, x);
   const int n = c.P->n_te;
   double s;
   if (n < 8) {
@@ -426,10 +437,11 @@ struct Lbfgsb {
       const double rt2 = t2_rcp_for_div(t2), rt2p = t2_rcp_for_div(t2p);
       // both quotients of a term share one reciprocal per noise level (1 / (2 sigma^2) is half of 1 / sigma^2, exactly)
       const double rs2 = t2_rcp_for_div(sg2), rsp2 = t2_rcp_for_div(sgp2);
-      auto term = [](double kk, double E, double s2v, double rs2v, double ls2v, float yf) {
+      const bool legacy = P.numpy_legacy != 0;
+      auto term = [legacy](double kk, double E, double s2v, double rs2v, double ls2v, float yf) {
         const double m = kk * E;
         const double xx = t2_div_by_rcp(m * (double)yf, s2v, rs2v);
-        const double a = (double)logf(yf) - ls2v;
+        const double a = rician_log_term(logf(yf), ls2v, legacy);
         const double b = t2_div_by_rcp((double)(yf * yf) + m * m, 2.0 * s2v, 0.5 * rs2v);
         const double dd = (xx < 0 ? -xx : xx) + t2_log(t2_i0e(xx));
         return (a - b) + dd;

@@ -68,8 +68,11 @@ def set_fit_params(args):
 
 
 def make_config(fit: str, fit_params: dict, TEeffs, prior: bool = True, norm: bool = False,
-                solver: str = "lbfgsb", precision: str = "f64") -> _abi.T2FitConfig:
-    """Flatten (fit, fit_params, TEeffs, prior, norm) into the ABI struct."""
+                solver: str = "lbfgsb", precision: str = "f64", numpy_legacy: bool = False) -> _abi.T2FitConfig:
+    """Flatten (fit, fit_params, TEeffs, prior, norm) into the ABI struct.  ``numpy_legacy``: reproduce the reference
+    as it runs under the numpy < 2 it freezes (requirements_frozen.txt:103) instead of under numpy >= 2: float32
+    log term of the rician objective (run_t2mapping.py:169), float32 prediction of the residual map
+    (utils/t2map_utils.py:74-80)."""
     if fit not in _abi.MODELS:
         raise ValueError(f"unknown fit {fit!r}")
     if fit_params.get("solver", "L-BFGS-B") != "L-BFGS-B":
@@ -103,6 +106,7 @@ def make_config(fit: str, fit_params: dict, TEeffs, prior: bool = True, norm: bo
         cfg.te_ms[i] = float(te[i]) if i < te.size else 0.0
     cfg.no_prior = int(not prior)
     cfg.norm = int(bool(norm))
+    cfg.numpy_legacy = int(bool(numpy_legacy))
     cfg.solver = _abi.SOLVERS[solver]
     cfg.precision = _abi.PRECISIONS[precision]
     if cfg.solver == _abi.SOLVER_LOGLIN and fit != "gaussian":
@@ -213,7 +217,8 @@ def _layout_of(echoes_shape, n_te, layout):
 
 
 def fit_volume(echoes, mask, TEeffs, fit, fit_params, prior=True, norm=False, *, layout="te_major",
-               solver="lbfgsb", precision="f64", extras=False, strict=True, device=0, out: T2Maps = None):
+               solver="lbfgsb", precision="f64", extras=False, strict=True, device=0, out: T2Maps = None,
+               numpy_legacy=False):
     """Fit every masked voxel and return the maps (run_t2mapping.py:411-461).
 
     ``echoes``: float32 ``(nTE, Z, Y, X)`` (``layout='te_major'``, the per-TE volumes as read) or
@@ -223,7 +228,7 @@ def fit_volume(echoes, mask, TEeffs, fit, fit_params, prior=True, norm=False, *,
     asynchronous on the current stream).  ``strict``: raise ValueError, as the reference's scipy call
     does, if a voxel's data-dependent bounds are infeasible (numpy path; the torch path never syncs).
     """
-    cfg = make_config(fit, fit_params, TEeffs, prior, norm, solver, precision)
+    cfg = make_config(fit, fit_params, TEeffs, prior, norm, solver, precision, numpy_legacy)
     lib = require_gpu()
     lay, spatial = _layout_of(echoes.shape, cfg.n_te, layout)
     n = int(np.prod(spatial)) if len(spatial) else 1
@@ -312,12 +317,12 @@ def _new_map(shape, dtype):
 # voxel seam
 # --------------------------------------------------------------------------------------------
 def fit_voxels(indices, fit, fit_params, TEeffs, reshaped_t2w, prior, norm, *, solver="lbfgsb",
-               precision="f64", device=0):
+               precision="f64", device=0, numpy_legacy=False):
     """Batched ``fit_voxel``: rows ``indices`` of the (N, nTE) float32 stack.
 
     Returns ``(x (M,n_par) f64, success (M,) bool, nit (M,) int32, fun (M,) f64, status (M,) u8)``.
     """
-    cfg = make_config(fit, fit_params, TEeffs, prior, norm, solver, precision)
+    cfg = make_config(fit, fit_params, TEeffs, prior, norm, solver, precision, numpy_legacy)
     lib = require_gpu()
     data = np.ascontiguousarray(reshaped_t2w, dtype=np.float32)
     if data.ndim != 2 or data.shape[1] != cfg.n_te:
@@ -336,10 +341,10 @@ def fit_voxels(indices, fit, fit_params, TEeffs, reshaped_t2w, prior, norm, *, s
 
 
 def fit_voxels_trace(indices, fit, fit_params, TEeffs, reshaped_t2w, prior, norm, *, trace_cap=64, solver="lbfgsb",
-                     precision="f64", device=0):
+                     precision="f64", device=0, numpy_legacy=False):
     """``fit_voxels`` plus, per voxel, the reference's ``iteration_info`` (run_t2mapping.py:180-234): a
     list of ``{'f_val', 'grad_norm': None, 'step_size'}`` dicts, one per iteration (at most ``trace_cap``)."""
-    cfg = make_config(fit, fit_params, TEeffs, prior, norm, solver, precision)
+    cfg = make_config(fit, fit_params, TEeffs, prior, norm, solver, precision, numpy_legacy)
     lib = require_gpu()
     data = np.ascontiguousarray(reshaped_t2w, dtype=np.float32)
     idx = np.ascontiguousarray(np.atleast_1d(indices), dtype=np.int64)
@@ -388,14 +393,14 @@ def fit_voxel(voxel, fit, fit_params, TEeffs, reshaped_t2w, prior, norm, want_tr
 # residual map
 # --------------------------------------------------------------------------------------------
 def compute_residuals(reshaped_t2w, TEeffs, fit, norm, k_map, t2_map, sigma_map, res_map, mask_indices, mask,
-                      device=0):
+                      device=0, numpy_legacy=False):
     """utils/t2map_utils.py:62-89 with the reference's signature; evaluated on the GPU."""
     import torch
 
     lib = require_gpu()
     data = np.ascontiguousarray(reshaped_t2w, dtype=np.float32)
     n, n_te = data.shape
-    cfg = make_config(fit, fit_table(fit, True), TEeffs, True, norm)
+    cfg = make_config(fit, fit_table(fit, True), TEeffs, True, norm, numpy_legacy=numpy_legacy)
     dev = torch.device("cuda", device)
     e = torch.from_numpy(data).to(dev)
     sel = torch.zeros(n, dtype=torch.uint8, device=dev)

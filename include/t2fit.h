@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define T2FIT_ABI_VERSION 3
+#define T2FIT_ABI_VERSION 4
 #define T2FIT_MAX_TE 32
 
 /* error codes */
@@ -83,7 +83,12 @@ typedef struct t2fit_config {
   int32_t maxls;              /* L-BFGS-B line-search step cap ("maxls", 50 in every table)    */
   int32_t maxiter;            /* iteration cap: scipy default 15000 (L-BFGS-B); LM default 60  */
   int32_t maxfun;             /* objective-evaluation cap (scipy default 15000)                */
-  int32_t reserved0;
+  int32_t numpy_legacy;       /* 0 (default): float promotion of numpy >= 2 (NEP 50), what the image's numpy does.
+                                 1: value-based casting of numpy < 2 -- the reference freezes numpy 1.26.0
+                                 (requirements_frozen.txt:103).  Two places on the path differ: the rician
+                                 objective's  np.log(signal) - np.log(sigma**2)  (run_t2mapping.py:169) is then a
+                                 FLOAT32 subtraction, and the residual map's prediction  k_map * np.exp(-te / t2_map)
+                                 (utils/t2map_utils.py:74-80) is float32 throughout.  (ABI 4; was reserved0.)   */
   int32_t reserved1;
   double te_ms[T2FIT_MAX_TE]; /* echo times [ms], ascending                                     */
   double x0[3];               /* initial_guess (k, T2, sigma); clipped into the bounds as scipy does */

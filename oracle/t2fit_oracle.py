@@ -98,7 +98,21 @@ def _obj_rician(p, te, y):
     return -ll
 
 
+def _obj_rician_legacy(p, te, y):
+    """run_t2mapping.py:157-177 as numpy < 2 evaluates it (the reference freezes numpy 1.26.0,
+    requirements_frozen.txt:103): ``np.log(signal) - np.log(sigma**2)`` is float32 array - float64 scalar, which
+    value-based casting keeps in FLOAT32 (numpy >= 2, NEP 50: float64).  Written with explicit casts so that it
+    means the same under either numpy.  Everything else in the objective is float64 under both."""
+    k, t2, sigma = p
+    m = k * np.exp(-te / t2)
+    x = (m * y) / (sigma ** 2)
+    a = np.log(y).astype(np.float32) - np.float32(np.log(sigma ** 2))
+    ll = np.sum(a - (y ** 2 + m ** 2) / (2 * sigma ** 2) + (np.abs(x) + np.log(i0e(x))))
+    return -ll
+
+
 _OBJ = {"gaussian": _obj_gauss, "gaussian_rician": _obj_gauss_rician, "rician": _obj_rician}
+_OBJ_LEGACY = {"gaussian": _obj_gauss, "gaussian_rician": _obj_gauss_rician, "rician": _obj_rician_legacy}
 
 
 def objective(mode, p, te, y):
@@ -109,11 +123,12 @@ class VoxelBoundsError(ValueError):
     """The reference aborts the whole volume here (scipy raises lb>ub)."""
 
 
-def fit_voxel(voxel, fit, fit_params, TEeffs, reshaped_t2w, prior, norm, want_trace=True):
+def fit_voxel(voxel, fit, fit_params, TEeffs, reshaped_t2w, prior, norm, want_trace=True, numpy_legacy=False):
     """One voxel, exactly as run_t2mapping.py:237-312 drives scipy.
 
     Returns ``(x f64[n_par], success, nit, fun, iteration_info)``; like the reference it mutates
-    ``fit_params['param_bounds']`` when ``prior`` is False (:243-245).
+    ``fit_params['param_bounds']`` when ``prior`` is False (:243-245).  ``numpy_legacy``: evaluate the objective
+    with the promotion rules of numpy < 2 (see ``_obj_rician_legacy``; only the rician objective differs).
     """
     row = reshaped_t2w[voxel, :]
     y = row / np.max(row) if norm else row
@@ -121,7 +136,7 @@ def fit_voxel(voxel, fit, fit_params, TEeffs, reshaped_t2w, prior, norm, want_tr
         fit_params["param_bounds"][0] = (reshaped_t2w[voxel, 0], 10000)
         fit_params["param_bounds"][1] = (10, 2000)
     y = np.array(y)
-    fun = _OBJ[fit]
+    fun = (_OBJ_LEGACY if numpy_legacy else _OBJ)[fit]
     trace, prev = [], [None]
 
     def _cb(xk):  # run_t2mapping.py:180-234: f at xk, ||xk - x_prev||
@@ -135,12 +150,20 @@ def fit_voxel(voxel, fit, fit_params, TEeffs, reshaped_t2w, prior, norm, want_tr
     return res.x, res.success, res.nit, res.fun, trace
 
 
-def compute_residuals(reshaped_t2w, TEeffs, fit, norm, k_map, t2_map, sigma_map, res_map, mask_indices):
+def compute_residuals(reshaped_t2w, TEeffs, fit, norm, k_map, t2_map, sigma_map, res_map, mask_indices,
+                      numpy_legacy=False):
     """utils/t2map_utils.py:62-89 on flat maps (the caller reshapes).  numpy-2 promotion: the
-    np.float64 TE scalar makes the prediction float64, which is then stored as float32."""
+    np.float64 TE scalar makes the prediction float64, which is then stored as float32.  ``numpy_legacy``: the
+    numpy < 2 rule instead -- the scalar takes the float32 of the maps and the whole prediction is float32."""
     pred = np.zeros_like(reshaped_t2w)
     with np.errstate(all="ignore"):
         for i, te in enumerate(TEeffs):
+            if numpy_legacy:
+                if fit == "gaussian":
+                    pred[:, i] = k_map * np.exp(np.float32(-te) / t2_map)
+                else:
+                    pred[:, i] = np.sqrt(k_map ** 2 * np.exp(np.float32(-2 * te) / t2_map) + sigma_map ** 2)
+                continue
             if fit == "gaussian":
                 pred[:, i] = k_map * np.exp(-te / t2_map)
             else:

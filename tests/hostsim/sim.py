@@ -36,7 +36,7 @@ def lib():
     return _lib
 
 
-def config(mode: str, low_field: bool, te, prior=True, norm=False, solver="lbfgsb", precision="f64"):
+def config(mode: str, low_field: bool, te, prior=True, norm=False, solver="lbfgsb", precision="f64", numpy_legacy=False):
     cfg = _abi.T2FitConfig()
     assert lib().hostsim_config_default(C.byref(cfg), _abi.MODELS[mode], int(low_field)) == 0
     te = np.asarray(te, np.float64)
@@ -45,6 +45,7 @@ def config(mode: str, low_field: bool, te, prior=True, norm=False, solver="lbfgs
         cfg.te_ms[i] = t
     cfg.no_prior = int(not prior)
     cfg.norm = int(norm)
+    cfg.numpy_legacy = int(numpy_legacy)
     cfg.solver = _abi.SOLVERS[solver]
     cfg.precision = _abi.PRECISIONS[precision]
     if solver == "lm":

@@ -343,6 +343,77 @@ def test_lbfgsb_stable_set(t2, model):
 
 
 # ---------------------------------------------------------------------------------------------
+# the reference under the stack it FREEZES (numpy 1.26 / Fortran L-BFGS-B): tests/golden/frozen_voxels_*.npz
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("model", ["gaussian", "gaussian_rician", "rician"])
+def test_lbfgsb_frozen_stack_stable_set(t2, model):
+    """The reference pins numpy 1.26.0 / scipy 1.11.3 (requirements_frozen.txt:103,144); the default fixtures come
+    from numpy 2.2 / scipy 1.15 (C translation of L-BFGS-B).  tests/golden/make_golden_frozen.py ran the reference
+    under the container's numpy 1.26.4 / scipy 1.7.1 (Fortran L-BFGS-B, the old promotion rules) on the same inputs.
+    HIP with cfg.numpy_legacy = 1 on the rows that are stable under BOTH stacks' one-ulp perturbations (for the
+    rician model, whose numpy-2 trajectory is a different one, under the frozen stack's): T2 within 1 ms on
+    >= 99.9 %, `success` equal on all, `nit` equal on >= 99.5 %, at most one row off per fixture.  For the two
+    least-squares models numpy_legacy changes nothing in the fit (asserted: bit-identical x with the switch off)."""
+    nf = _floor()
+    n_stable = n_t2 = n_nit = n_ok = 0
+    for path in [f for f in FILES if os.path.basename(f)[10:].startswith(model + "_prior") or
+                 os.path.basename(f)[10:].startswith(model + "_noprior")]:
+        d = np.load(path)
+        name = os.path.basename(path)[7:-4]
+        fz = np.load(os.path.join(GOLDEN, f"frozen_voxels_{name}.npz"))
+        stable = fz["stable"] & (nf[name + "/stable"] if model != "rician" else True)
+        rows = np.flatnonzero(stable)
+        x, ok, nit, fun, st = t2.fit_voxels(rows, model, _table(t2, d), d["te"], d["y"], bool(d["prior"]), False,
+                                            numpy_legacy=True)
+        if model != "rician":
+            x0 = t2.fit_voxels(rows, model, _table(t2, d), d["te"], d["y"], bool(d["prior"]), False)[0]
+            assert np.array_equal(x, x0)
+        off = np.abs(x[:, 1] - fz["x"][rows, 1]) > T2_TOL_MS
+        assert off.sum() <= 1, (name, rows[off])
+        n_stable += len(rows)
+        n_t2 += int(off.sum())
+        n_nit += int(np.sum(nit != fz["nit"][rows]))
+        n_ok += int(np.sum(ok != fz["success"][rows]))
+    assert n_stable >= 900, n_stable
+    assert n_ok == 0
+    assert n_t2 <= 1e-3 * n_stable, (n_t2, n_stable)
+    assert n_nit <= 5e-3 * n_stable, (n_nit, n_stable)
+
+
+def test_rician_numpy2_and_numpy1_trajectories_are_different_ones(t2):
+    """Why the switch exists: on the frozen stack's stable rician rows the default (numpy >= 2) form ends more than
+    1 ms away from the frozen-stack reference on a large share of the rows, the legacy form on (almost) none."""
+    d = np.load(os.path.join(GOLDEN, "voxels_lf_rician_prior_te6.npz"))
+    fz = np.load(os.path.join(GOLDEN, "frozen_voxels_lf_rician_prior_te6.npz"))
+    rows = np.flatnonzero(fz["stable"])
+    new = t2.fit_voxels(rows, "rician", _table(t2, d), d["te"], d["y"], True, False)[0]
+    old = t2.fit_voxels(rows, "rician", _table(t2, d), d["te"], d["y"], True, False, numpy_legacy=True)[0]
+    assert np.mean(np.abs(new[:, 1] - fz["x"][rows, 1]) > T2_TOL_MS) >= 0.2
+    assert np.sum(np.abs(old[:, 1] - fz["x"][rows, 1]) > T2_TOL_MS) <= 1
+
+
+@pytest.mark.parametrize("name", ["lf_gaussian_prior_te6", "hf_gaussian_rician_noprior_te8", "lf_rician_prior_te3"])
+def test_residual_map_frozen_stack(t2, name):
+    """compute_residuals (utils/t2map_utils.py:62-89) as numpy 1.26 evaluates it -- float32 prediction throughout --
+    on the frozen-stack reference's own parameters: within RES_TOL of its residual map with cfg.numpy_legacy = 1
+    (float32 exp of the device library against numpy's), and the float64-prediction form is measurably another map."""
+    d = np.load(os.path.join(GOLDEN, f"voxels_{name}.npz"))
+    fz = np.load(os.path.join(GOLDEN, f"frozen_voxels_{name}.npz"))
+    mode = str(d["mode"])
+    rows = np.flatnonzero(~fz["raised"] & np.isfinite(fz["res"]))
+    m = d["y"].shape[0]
+    k, tt, sg = (np.zeros(m, np.float32) for _ in range(3))
+    k[rows], tt[rows] = fz["x"][rows, 0], fz["x"][rows, 1]
+    if fz["x"].shape[1] == 3:
+        sg[rows] = fz["x"][rows, 2]
+    tt[tt == 0] = 1.0  # rows the reference could not fit: keep the division defined, they are not compared
+    got = t2.compute_residuals(d["y"], d["te"], mode, False, k, tt, sg, np.zeros(m, np.float32), rows,
+                               np.zeros((m, 1, 1), bool), numpy_legacy=True).reshape(-1)
+    assert np.max(np.abs(got[rows] - fz["res"][rows])) <= RES_TOL
+    assert np.mean(np.abs(got[rows] - fz["res"][rows]) <= 1e-4) >= 0.9
+
+
+# ---------------------------------------------------------------------------------------------
 # parity at scale: 20 000 voxels per configuration against the live oracle on the box's host cores
 # ---------------------------------------------------------------------------------------------
 AT_SCALE_N = 20000

@@ -136,3 +136,51 @@ def test_notebook_known_answer():
     assert ok and nit == 13                      # the notebook prints nit: 13 (nfev: 78)
     assert abs(x[1] - 117.6) < 0.03 * 117.6 and abs(x[0] - 369.3) < 0.03 * 369.3   # means vs the unprinted medians
     assert abs(x[0] - 363.9) < 0.1 and abs(x[1] - 120.6) < 0.1                      # SURVEY.md's measurement here
+
+
+# ---- the reference under the stack it freezes (tests/golden/make_golden_frozen.py) -----------------------------
+def test_frozen_fixture_inventory():
+    """36 frozen_voxels_*.npz, generated under numpy 1.26.x / scipy 1.7.1 (Fortran L-BFGS-B) from the very rows of the
+    default fixtures (checksum), with a non-trivial stable set each."""
+    import zlib
+
+    for path in FILES:
+        name = os.path.basename(path)[7:-4]
+        fz = np.load(os.path.join(os.path.dirname(path), f"frozen_voxels_{name}.npz"))
+        d = np.load(path)
+        assert str(fz["numpy_version"]).startswith("1.26") and str(fz["scipy_version"]) == "1.7.1"
+        assert int(fz["y_crc"]) == zlib.crc32(np.ascontiguousarray(d["y"]).tobytes())
+        assert np.array_equal(fz["raised"], d["raised"]) and fz["x"].shape == d["x"].shape
+        assert int(fz["stable"].sum()) >= 30, name
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[7:-4] for f in FILES])
+def test_oracle_against_the_frozen_stack(path):
+    """The oracle (this interpreter: numpy 2 / scipy 1.15, with `numpy_legacy=True` restating the old promotion rule
+    by explicit casts) against the reference run under numpy 1.26 / Fortran L-BFGS-B, on the rows stable under both
+    stacks' one-ulp perturbations (rician: the frozen stack's): T2 within 1 ms on all but one row, `success` equal.
+    The residual map in its float32 form is the frozen stack's BIT FOR BIT (same float32 exp in both numpys)."""
+    d = np.load(path)
+    name = os.path.basename(path)[7:-4]
+    fz = np.load(os.path.join(os.path.dirname(path), f"frozen_voxels_{name}.npz"))
+    floor = np.load(os.path.join(os.path.dirname(path), "noise_floor.npz"))
+    mode, low_field, prior = str(d["mode"]), bool(d["low_field"]), bool(d["prior"])
+    rows = np.flatnonzero(fz["stable"] & (floor[name + "/stable"] if mode != "rician" else True))[::3]
+    fp = O.fit_table(mode, low_field)
+    off = 0
+    for v in rows:
+        with np.errstate(all="ignore"):
+            x, ok, nit, f, _ = O.fit_voxel(int(v), mode, fp, d["te"], d["y"], prior, False, want_trace=False,
+                                           numpy_legacy=True)
+        assert ok == fz["success"][v]
+        off += abs(x[1] - fz["x"][v, 1]) > 1.0
+    assert off <= 1, (name, off, len(rows))
+    m = d["y"].shape[0]
+    okrows = np.where(~fz["raised"])[0]
+    k, t2, sg = (np.zeros(m, np.float32) for _ in range(3))
+    k[okrows], t2[okrows] = fz["x"][okrows, 0], fz["x"][okrows, 1]
+    if fz["x"].shape[1] == 3:
+        sg[okrows] = fz["x"][okrows, 2]
+    res = O.compute_residuals(d["y"], d["te"], mode, False, k, t2, sg, np.zeros(m, np.float32), okrows, numpy_legacy=True)
+    fin = np.isfinite(fz["res"])
+    assert np.array_equal(res[fin], fz["res"][fin])
