@@ -326,8 +326,10 @@ template <int MODEL, int NTE = 0> struct LbfgsbLane {
   static constexpr int kNte = NTE;  // > 0: the echo count is a compile-time constant (the refill loops flatten too)
   static constexpr int kHistDoubles = Solver::M * Solver::PAIR;  // correction pairs, per lane, in LDS
   static constexpr int kWavesPerSimd = 1;
-  // one-wave workgroups, two waves on a SIMD: the Rician lane (i0e) needs more than the 256 registers that allows
-  static constexpr bool kWaveWgOk = MODEL != T2FIT_MODEL_RICIAN;
+  // one-wave workgroups, two waves on a SIMD (256 registers): every model.  (The Rician-likelihood lane needed 370
+  // registers while its evaluation was unrolled over echoes and i0e coefficients; as loops -- t2fit_lbfgsb.h eval(),
+  // t2fit_lane.h t2_log_i0e4 -- it fits.)
+  static constexpr bool kWaveWgOk = true;
 #ifndef T2_WAVE_HINT_2PAR
 #define T2_WAVE_HINT_2PAR 2
 #endif
@@ -960,7 +962,7 @@ hipError_t launch_lbfgsb(int n_te, bool large, unsigned grid, size_t lds_samples
     if (n_te == 6) return launch_persistent<LbfgsbLane<MODEL, 6>, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);
     if (n_te == 3) return launch_persistent<LbfgsbLane<MODEL, 3>, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);
     // 7 / 5 / 4 echoes: the one-wave-workgroup kernels only (16.2 -> 12.6 ms at 5 echoes against the generic lane)
-    if constexpr (MODEL != T2FIT_MODEL_RICIAN) {
+    {
       hipError_t e = hipErrorNotSupported;
       if (g_wave_wg == 1) {
         if (n_te == 7) e = launch_persistent<LbfgsbLane<MODEL, 7>, true, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);

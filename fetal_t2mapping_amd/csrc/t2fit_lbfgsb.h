@@ -37,12 +37,6 @@
 
 #include "t2fit_lane.h"
 
-#if defined(__HIPCC__)
-#define T2_UNROLL _Pragma("unroll")
-#else
-#define T2_UNROLL
-#endif
-
 // Diagnostic build (-DT2_PHASE_STAMPS) only: wave-level cost of each block of the lane solver.  T2_BLK_END adds, for
 // block i, the shader cycles since the matching T2_BLK_T0, the number of lanes that were active in it and one
 // entry to three counters of the wave's own LDS block (c.diag); the kernel adds them up over the grid at exit.
@@ -306,6 +300,72 @@ struct NpSum {
 };
 
 
+// Four row sums (the four objective values of one forward-difference evaluation) in numpy's float64 add.reduce order,
+// fed one echo at a time from a run-time loop over the echoes: the echo index is wave-uniform, so what to do with an
+// item is decided by scalar branches.  NTE in 1..7: the plain left-to-right sum; NTE == 8: the balanced tree over
+// pairs, quads and halves with three carried values per sum; NTE == 0 (run-time n, 2..32): the general pairwise form
+// -- below eight items left to right, otherwise eight interleaved partial sums over the first n - n % 8 items, combined
+// as a balanced tree, then the remaining items one by one.
+template <int NTE> struct RowSums4 {
+  static constexpr bool kGeneral = NTE == 0, kTree = NTE == 8;
+  double s[kTree ? 1 : 4];              // left-to-right sum; general form: tree total + tail
+  double p[kTree ? 4 : 1], q[kTree ? 4 : 1], h[kTree ? 4 : 1];  // NTE == 8: pair, quad, first half
+  double r[kGeneral ? 8 : 1][4];        // general form: the eight interleaved partial sums
+  T2_HD void init() {
+    if constexpr (!kTree) {
+      T2_UNROLL
+      for (int j = 0; j < 4; ++j) s[j] = 0.0;
+    }
+    if constexpr (kGeneral) {
+      T2_UNROLL
+      for (int q8 = 0; q8 < 8; ++q8)
+        T2_UNROLL
+        for (int j = 0; j < 4; ++j) r[q8][j] = 0.0;
+    }
+  }
+  T2_HD void add(int i, int n, const double* t) {
+    if constexpr (kTree) {
+      T2_UNROLL
+      for (int j = 0; j < 4; ++j) {
+        if ((i & 1) == 0) { p[j] = t[j]; continue; }
+        p[j] += t[j];
+        if ((i & 2) == 0) { q[j] = p[j]; continue; }
+        q[j] += p[j];
+        if ((i & 4) == 0) h[j] = q[j];
+      }
+    } else if constexpr (kGeneral) {
+      const int n8 = n & ~7;
+      if (n < 8 || i >= n8) {
+        T2_UNROLL
+        for (int j = 0; j < 4; ++j) s[j] += t[j];
+        return;
+      }
+      // (every slot is rewritten, the one in turn with its new value: written as eight guarded stores the optimiser
+      // turns the guard into an index and the array goes to scratch memory)
+      const int slot = i & 7;
+      static_for<0, 8>([&](auto SC) {
+        constexpr int S = decltype(SC)::value;
+        T2_UNROLL
+        for (int j = 0; j < 4; ++j) {
+          const double nv = i < 8 ? t[j] : r[S][j] + t[j];
+          r[S][j] = slot == S ? nv : r[S][j];
+        }
+      });
+      if (i == n8 - 1) {
+        T2_UNROLL
+        for (int j = 0; j < 4; ++j) s[j] = ((r[0][j] + r[1][j]) + (r[2][j] + r[3][j])) + ((r[4][j] + r[5][j]) + (r[6][j] + r[7][j]));
+      }
+    } else {
+      T2_UNROLL
+      for (int j = 0; j < 4; ++j) s[j] += t[j];
+    }
+  }
+  T2_HD double total(int j) const {
+    if constexpr (kTree) return h[j] + q[j];
+    else return s[j];
+  }
+};
+
 // ---- the solver -----------------------------------------------------------------------------------
 // Resumable (reverse-communication) form, like the library's own driver loop: the caller evaluates
 // the objective and its forward-difference gradient at `x` with eval(), then calls advance(), which
@@ -318,6 +378,7 @@ struct NpSum {
 template <int MODEL, int NTE = 0>
 struct Lbfgsb {
   static constexpr int N = MODEL == T2FIT_MODEL_GAUSSIAN ? 2 : 3;
+  static constexpr int kNte = NTE;
   static constexpr int M = 10;
   static constexpr int PAIR = 2 * N - 1;  // doubles per correction pair in the ring (see load_s / store_s)
 
@@ -376,7 +437,7 @@ struct Lbfgsb {
       dx[i] = x1[i] - x[i];
     }
     nfev += 1 + N;
-    if (n >= 16) {  // long echo trains: one objective at a time (general pairwise summation)
+    if (MODEL != T2FIT_MODEL_RICIAN && n >= 16) {  // long echo trains: one objective at a time (general pairwise summation)
       f = objective_t<MODEL>(c, x);
       T2_UNROLL
       for (int i = 0; i < N; ++i) {
@@ -431,6 +492,11 @@ struct Lbfgsb {
       g[1] = t2_fdiv(mean(s2.total(n)) - f, dx[1]);
       g[N - 1] = t2_fdiv(mean(s3.total(n)) - f, dx[N - 1]);
     } else {
+      // Rician likelihood (run_t2mapping.py:157-177).  A real loop over the echoes, and inside it real loops over the
+      // Chebyshev coefficients of i0e (t2_log_i0e4): the evaluation is a few KB of code whatever the echo count, and its
+      // working set is what one echo needs.  With a compile-time echo count the samples live in registers, which a
+      // run-time index cannot address: the loop always reads ys[0] and rotates the array by one (NTE moves per echo;
+      // after NTE echoes it is back in order).
       const double k = x[0], kp = x1[0], t2 = x[1], t2p = x1[1];
       const double sg2 = x[N - 1] * x[N - 1], sgp2 = x1[N - 1] * x1[N - 1];
       const double ls2 = t2_log(sg2), lsp2 = t2_log(sgp2);
@@ -438,30 +504,43 @@ struct Lbfgsb {
       // both quotients of a term share one reciprocal per noise level (1 / (2 sigma^2) is half of 1 / sigma^2, exactly)
       const double rs2 = t2_rcp_for_div(sg2), rsp2 = t2_rcp_for_div(sgp2);
       const bool legacy = P.numpy_legacy != 0;
-      auto term = [legacy](double kk, double E, double s2v, double rs2v, double ls2v, float yf) {
-        const double m = kk * E;
-        const double xx = t2_div_by_rcp(m * (double)yf, s2v, rs2v);
-        const double a = rician_log_term(logf(yf), ls2v, legacy);
-        const double b = t2_div_by_rcp((double)(yf * yf) + m * m, 2.0 * s2v, 0.5 * rs2v);
-        const double dd = (xx < 0 ? -xx : xx) + t2_log(t2_i0e(xx));
-        return (a - b) + dd;
-      };
-      auto body = [&](int i, auto add) {
-        const float yf = smp(c, i);
+      RowSums4<NTE> sums;
+      sums.init();
+      T2_NOUNROLL
+      for (int i = 0; i < n; ++i) {
+        float yf;
+        if constexpr (NTE > 0) {
+          yf = ys[0];
+          T2_UNROLL
+          for (int j = 0; j + 1 < NTE; ++j) ys[j] = ys[j + 1];
+          ys[NTE - 1] = yf;
+        } else {
+          yf = c.sample(i);
+        }
         const double te = P.te[i];
         const double E = t2_exp_core(t2_div_by_rcp(-te, t2, rt2)), Ep = t2_exp_core(t2_div_by_rcp(-te, t2p, rt2p));
-        add(term(k, E, sg2, rs2, ls2, yf), term(kp, E, sg2, rs2, ls2, yf), term(k, Ep, sg2, rs2, ls2, yf),
-            term(k, E, sgp2, rsp2, lsp2, yf));
-      };
-      static_for<0, 8>([&](auto JC) {
-        constexpr int J = decltype(JC)::value;
-        if (J < n) body(J, [&](double a, double b2, double c2, double d2) { s0.add<J>(a); s1.add<J>(b2); s2.add<J>(c2); s3.add<J>(d2); });
-      });
-      for (int i = 8; i < n; ++i) body(i, [&](double a, double b2, double c2, double d2) { s0.tail(a); s1.tail(b2); s2.tail(c2); s3.tail(d2); });
-      f = -s0.total(n);
-      g[0] = t2_fdiv(-s1.total(n) - f, dx[0]);
-      g[1] = t2_fdiv(-s2.total(n) - f, dx[1]);
-      g[N - 1] = t2_fdiv(-s3.total(n) - f, dx[N - 1]);
+        const double yd = (double)yf, y2 = (double)(yf * yf);
+        const float ly = logf(yf);
+        // the four points: (k, T2, sigma), (k + h, ..), (.., T2 + h, ..), (.., .., sigma + h)
+        const double m[4] = {k * E, kp * E, k * Ep, k * E};
+        double xx[4], li[4], tm[4];
+        T2_UNROLL
+        for (int j = 0; j < 4; ++j) xx[j] = t2_div_by_rcp(m[j] * yd, j == 3 ? sgp2 : sg2, j == 3 ? rsp2 : rs2);
+        t2_log_i0e4(xx, li);
+        T2_UNROLL
+        for (int j = 0; j < 4; ++j) {
+          const double a = rician_log_term(ly, j == 3 ? lsp2 : ls2, legacy);
+          const double b = t2_div_by_rcp(y2 + m[j] * m[j], 2.0 * (j == 3 ? sgp2 : sg2), 0.5 * (j == 3 ? rsp2 : rs2));
+          const double dd = (xx[j] < 0 ? -xx[j] : xx[j]) + li[j];
+          tm[j] = (a - b) + dd;
+        }
+        sums.add(i, n, tm);
+      }
+      f = -sums.total(0);
+      // (k + h) - k and (T2 + h) - T2 once more: two subtractions instead of two values carried through the loop
+      g[0] = t2_fdiv(-sums.total(1) - f, kp - k);
+      g[1] = t2_fdiv(-sums.total(2) - f, t2p - t2);
+      g[N - 1] = t2_fdiv(-sums.total(3) - f, dx[N - 1]);
     }
   }
 

@@ -160,3 +160,72 @@ extern "C" int hostsim_pair_roundtrip(int dim, const double* s_in, int64_t n, do
   }
   return 0;
 }
+
+// log(i0e(x)) through the four-wide table-driven loop the Rician lane uses (out) and through the one-value Cephes
+// form it restates (ref): n groups of four arguments.
+extern "C" int hostsim_log_i0e4(const double* x, int64_t n, double* out, double* ref) {
+  for (int64_t v = 0; v < n; ++v) {
+    t2_log_i0e4(x + 4 * v, out + 4 * v);
+    for (int j = 0; j < 4; ++j) ref[4 * v + j] = t2_log(t2_i0e(x[4 * v + j]));
+  }
+  return 0;
+}
+
+// numpy's add.reduce order as the echo loop of the Rician evaluation accumulates it: terms[i * 4 + j] is item i of row
+// sum j; nte_special != 0 uses the compile-time echo-count form (n must then be 3..8), 0 the run-time form.
+extern "C" int hostsim_rowsums4(const double* terms, int n, int nte_special, double* out) {
+  auto run = [&](auto& s) {
+    s.init();
+    for (int i = 0; i < n; ++i) s.add(i, n, terms + 4 * i);
+    for (int j = 0; j < 4; ++j) out[j] = s.total(j);
+  };
+  if (!nte_special) { RowSums4<0> s; run(s); return 0; }
+  switch (n) {
+    case 3: { RowSums4<3> s; run(s); return 0; }
+    case 4: { RowSums4<4> s; run(s); return 0; }
+    case 5: { RowSums4<5> s; run(s); return 0; }
+    case 6: { RowSums4<6> s; run(s); return 0; }
+    case 7: { RowSums4<7> s; run(s); return 0; }
+    case 8: { RowSums4<8> s; run(s); return 0; }
+  }
+  return -1;
+}
+
+// the Rician objective and its forward-difference gradient at `x` as the lane solver evaluates them (run-time echo
+// count, or the echo-count specialisation when nte_special), next to the one-objective-at-a-time reference form
+// (objective_t / ObjTerm: the statement-by-statement restatement of run_t2mapping.py:157-177): out = f, g0, g1, g2;
+// ref = f(x), f(x + h e0), f(x + h e1), f(x + h e2) are not exposed -- ref[0] = objective_t at x only.
+extern "C" int hostsim_rician_eval(const t2fit_config* cfg, const float* row, const double* x, int nte_special, double* out,
+                                   double* ref) {
+  const LaneParams P = make_lane_params(*cfg);
+  float buf[T2FIT_MAX_TE];
+  for (int i = 0; i < cfg->n_te; ++i) buf[i] = row[i];
+  bool finite;
+  float y0_raw;
+  ObjCtx c = prepare_samples(P, buf, 1, finite, y0_raw);
+  double lb[3], ub[3];
+  lane_bounds(P, y0_raw, lb, ub);
+  double hist[60] = {};
+  auto run = [&](auto& s) {
+    s.init(x, lb, ub, hist, 1);
+    for (int j = 0; j < 3; ++j) s.x[j] = x[j];
+    if constexpr (std::remove_reference_t<decltype(s)>::kNte > 0)
+      for (int i = 0; i < std::remove_reference_t<decltype(s)>::kNte; ++i) s.ys[i] = buf[i];
+    s.eval(c);
+    out[0] = s.f; out[1] = s.g[0]; out[2] = s.g[1]; out[3] = s.g[2];
+    if constexpr (std::remove_reference_t<decltype(s)>::kNte > 0)  // the sample rotation must have come full circle
+      for (int i = 0; i < std::remove_reference_t<decltype(s)>::kNte; ++i)
+        if (s.ys[i] != buf[i]) out[0] = NAN;
+  };
+  ref[0] = objective_t<T2FIT_MODEL_RICIAN>(c, x);
+  if (!nte_special) { Lbfgsb<T2FIT_MODEL_RICIAN> s; run(s); return 0; }
+  switch (cfg->n_te) {
+    case 3: { Lbfgsb<T2FIT_MODEL_RICIAN, 3> s; run(s); return 0; }
+    case 4: { Lbfgsb<T2FIT_MODEL_RICIAN, 4> s; run(s); return 0; }
+    case 5: { Lbfgsb<T2FIT_MODEL_RICIAN, 5> s; run(s); return 0; }
+    case 6: { Lbfgsb<T2FIT_MODEL_RICIAN, 6> s; run(s); return 0; }
+    case 7: { Lbfgsb<T2FIT_MODEL_RICIAN, 7> s; run(s); return 0; }
+    case 8: { Lbfgsb<T2FIT_MODEL_RICIAN, 8> s; run(s); return 0; }
+  }
+  return -1;
+}

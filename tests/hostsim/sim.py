@@ -104,3 +104,35 @@ def pair_roundtrip(s):
     L.hostsim_pair_roundtrip.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
     assert L.hostsim_pair_roundtrip(s.shape[1], s.ctypes.data, len(s), out.ctypes.data) == 0
     return out
+
+
+def log_i0e4(x):
+    """x: (n, 4) float64 -> (four-wide table-driven loop, one-value Cephes form), both (n, 4)."""
+    L = lib()
+    x = np.ascontiguousarray(x, np.float64)
+    out, ref = np.empty_like(x), np.empty_like(x)
+    L.hostsim_log_i0e4.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    assert L.hostsim_log_i0e4(x.ctypes.data, len(x), out.ctypes.data, ref.ctypes.data) == 0
+    return out, ref
+
+
+def rowsums4(terms, nte_special):
+    """terms: (n, 4) float64 -> the four column sums as the Rician echo loop accumulates them."""
+    L = lib()
+    terms = np.ascontiguousarray(terms, np.float64)
+    out = np.zeros(4)
+    L.hostsim_rowsums4.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    assert L.hostsim_rowsums4(terms.ctypes.data, len(terms), int(nte_special), out.ctypes.data) == 0
+    return out
+
+
+def rician_eval(cfg, row, x, nte_special):
+    """(f, g0, g1, g2) of the lane solver's evaluation at x, and the one-at-a-time reference form's f(x)."""
+    L = lib()
+    row = np.ascontiguousarray(row, np.float32)
+    x = np.ascontiguousarray(x, np.float64)
+    out, ref = np.zeros(4), np.zeros(4)
+    L.hostsim_rician_eval.argtypes = [C.POINTER(_abi.T2FitConfig), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    rc = L.hostsim_rician_eval(C.byref(cfg), row.ctypes.data, x.ctypes.data, int(nte_special), out.ctypes.data, ref.ctypes.data)
+    assert rc == 0, rc
+    return out, ref[0]

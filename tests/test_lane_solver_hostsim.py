@@ -199,3 +199,63 @@ def test_correction_pair_ring_keeps_the_direction_of_s(dim):
     assert np.allclose(back, s[:, 1:], rtol=4e-16, atol=0.0)
     assert np.array_equal(got[:, 1:] == 0.0, s[:, 1:] == 0.0)
     assert small[:200].all() and small[440:480].all() and not small[200:440].any()
+
+
+# ---- the Rician evaluation as loops (round 3): each piece against the form it restates --------------------------
+def test_log_i0e_four_wide_loop_equals_the_cephes_form():
+    """t2_log_i0e4 (table-driven Chebyshev loops, four arguments at once, both series wave-uniform) against
+    log(i0e(x)) of the one-value Cephes form, bit for bit: both ranges, the boundary 8, mixed groups, 0, negative
+    arguments, huge arguments; and against scipy to 1e-13."""
+    from scipy.special import i0e
+
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(0, 8, (500, 4)), rng.uniform(8, 2000, (500, 4)), 10.0 ** rng.uniform(-6, 6, (500, 4)),
+                        -10.0 ** rng.uniform(-3, 3, (100, 4)),
+                        np.array([[0.0, 8.0, np.nextafter(8.0, 9.0), 1e300], [7.999, 8.001, -8.0, -0.0]])])
+    out, ref = sim.log_i0e4(x)
+    assert np.array_equal(out, ref)
+    assert np.allclose(out, np.log(i0e(x)), rtol=1e-13, atol=1e-15)
+    nan_out, nan_ref = sim.log_i0e4(np.array([[np.nan, 1.0, 100.0, np.inf]]))
+    assert np.array_equal(nan_out, nan_ref, equal_nan=True) and np.isnan(nan_out[0, 0])
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 8, 9, 11, 15, 16, 17, 24, 31, 32])
+def test_echo_loop_row_sums_are_numpys(n):
+    """RowSums4 fed item by item == np.sum of each column, bit for bit (numpy's pairwise order: left to right below
+    eight items, eight interleaved partial sums + tree + tail from eight on), in the run-time form for every n and
+    in the compile-time echo-count form for 3..8."""
+    rng = np.random.default_rng(n)
+    for _ in range(200):
+        t = rng.normal(size=(n, 4)) * 10.0 ** rng.integers(-4, 5, size=(n, 4))
+        want = np.array([np.sum(np.ascontiguousarray(t[:, j])) for j in range(4)])
+        assert np.array_equal(sim.rowsums4(t, False), want)
+        if 3 <= n <= 8:
+            assert np.array_equal(sim.rowsums4(t, True), want)
+
+
+@pytest.mark.parametrize("n_te", [3, 5, 6, 8, 9, 16, 20, 32])
+@pytest.mark.parametrize("legacy", [False, True])
+def test_rician_echo_loop_equals_the_statement_by_statement_objective(n_te, legacy):
+    """Lbfgsb<RICIAN>::eval (one loop over the echoes, four objective values at once) against objective_t (one
+    objective at a time, the reference's statements one by one): f(x) bit for bit, in the run-time echo-count form and
+    in the specialised forms (whose sample rotation must come back to where it started); the forward-difference
+    gradient against differences of the oracle's objective."""
+    from oracle import t2fit_oracle as oracle
+
+    rng = np.random.default_rng(100 + n_te)
+    te = np.round(np.linspace(30.0, 400.0, n_te))
+    cfg = sim.config("rician", True, te, numpy_legacy=legacy)
+    obj = oracle._OBJ_LEGACY["rician"] if legacy else oracle._OBJ["rician"]
+    for _ in range(40):
+        k, t2v, sg = rng.uniform(560, 890), rng.uniform(20, 500), rng.choice([3.0, 20.0, 40.0, 300.0, 900.0])
+        clean = k * np.exp(-te / t2v)
+        row = np.hypot(clean + rng.normal(size=n_te) * sg, rng.normal(size=n_te) * sg).astype(np.float32)
+        x = np.array([rng.uniform(551, 899), rng.uniform(11, 599), rng.uniform(2.1, 999)])
+        for special in ([False, True] if n_te <= 8 else [False]):
+            out, ref = sim.rician_eval(cfg, row, x, special)
+            assert out[0] == ref, (n_te, special, out[0], ref)
+        with np.errstate(all="ignore"):
+            f0 = obj(x, te, row)
+            grad = [(obj(x + 1e-8 * np.eye(3)[j], te, row) - f0) / ((x[j] + 1e-8) - x[j]) for j in range(3)]
+        assert np.isclose(out[0], f0, rtol=1e-6)  # np.log of a float32 array is not glibc's logf to the last bit: a constant shift
+        assert np.allclose(out[1:], grad, rtol=1e-5, atol=2e-3)  # differences of nearly equal numbers: libm last bits
