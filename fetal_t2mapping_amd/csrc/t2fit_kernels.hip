@@ -320,11 +320,14 @@ constexpr int kPlaceWords = 0;
 constexpr int kCounterWords = 16 + kDiagWords + kPlaceWords;    // chunk counter + diagnostic totals
 
 // what the persistent kernel needs to know about a resumable lane solver
-template <int MODEL, int NTE = 0> struct LbfgsbLane {
-  using Solver = Lbfgsb<MODEL, NTE>;
+template <int MODEL, int NTE = 0, bool GSPLIT = false> struct LbfgsbLane {
+  using Solver = Lbfgsb<MODEL, NTE, GSPLIT>;
+  // the one-wave-workgroup kernels keep one number of each pair in global memory (three parameters: eight waves per CU)
+  using WaveWg = LbfgsbLane<MODEL, NTE, MODEL != T2FIT_MODEL_GAUSSIAN>;
+  static constexpr bool kGlobalPart = Solver::kSplit;
   static constexpr int NP = Solver::N;
   static constexpr int kNte = NTE;  // > 0: the echo count is a compile-time constant (the refill loops flatten too)
-  static constexpr int kHistDoubles = Solver::M * Solver::PAIR;  // correction pairs, per lane, in LDS
+  static constexpr int kHistDoubles = Solver::M * Solver::PAIR_L;  // correction pairs, per lane, in LDS
   static constexpr int kWavesPerSimd = 1;
   // one-wave workgroups, two waves on a SIMD (256 registers): every model.  (The Rician-likelihood lane needed 370
   // registers while its evaluation was unrolled over echoes and i0e coefficients; as loops -- t2fit_lbfgsb.h eval(),
@@ -339,7 +342,7 @@ template <int MODEL, int NTE = 0> struct LbfgsbLane {
   static constexpr int kRefillMin = 8;   // measured on MI355X: 1 -> 28.1 ms, 8 -> 26.8 ms, 16 -> 27.6 ms
   static constexpr bool kSplit = true;   // advance() = digest() + begin(): the kernel may batch begin() (T2FIT_PARK_MIN)
   __device__ static void init(Solver& s, const ObjCtx&, const double* x0, const double* lb, const double* ub,
-                              double* hist, int hstride) { s.init(x0, lb, ub, hist, hstride); }
+                              double* hist, int hstride, double* ghist) { s.init(x0, lb, ub, hist, hstride, ghist, 64); }
   __device__ static void result(const Solver& s, const ObjCtx&, LaneResult& r) { s.result(r); }
   template <int J> __device__ static void take_sample(Solver& s, float y) {
     if constexpr (NTE > 0 && J < NTE) s.ys[J] = y;
@@ -347,6 +350,8 @@ template <int MODEL, int NTE = 0> struct LbfgsbLane {
 };
 template <typename T, int NPAR, int NTE = 0> struct LmLaneAdaptor {
   using Solver = LmLane<T, NPAR, NTE>;
+  using WaveWg = LmLaneAdaptor<T, NPAR, NTE>;
+  static constexpr bool kGlobalPart = false;
   static constexpr int NP = NPAR;
   static constexpr int kNte = NTE;
   static constexpr int kHistDoubles = 0;
@@ -357,7 +362,7 @@ template <typename T, int NPAR, int NTE = 0> struct LmLaneAdaptor {
   static constexpr int kRefillMin = 24;  // measured (f32, 3 parameters, MI355X): 8 -> 1.62 ms, 16 -> 1.42 ms, 24 -> 1.35 ms, 32 -> 1.35 ms
   static constexpr bool kSplit = false;
   __device__ static void init(Solver& s, const ObjCtx& c, const double* x0, const double* lb, const double* ub,
-                              double*, int) { s.init(c, x0, lb, ub); }
+                              double*, int, double*) { s.init(c, x0, lb, ub); }
   __device__ static void result(const Solver& s, const ObjCtx& c, LaneResult& r) { s.result(c, r); }
   template <int J> __device__ static void take_sample(Solver&, float) {}
 };
@@ -365,7 +370,8 @@ template <typename T, int NPAR, int NTE = 0> struct LmLaneAdaptor {
 template <class A, int kChunk, bool kTrace, bool kExtras, int kWg = kBlock, bool kRegs = false>
 __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float* __restrict__ echoes, int layout,
                                                const uint8_t* __restrict__ mask, int64_t n_vox, const DevMaps& m,
-                                               unsigned long long* next_chunk, int refill_min, int park_min, int take) {
+                                               unsigned long long* next_chunk, int refill_min, int park_min, int take,
+                                               double* ghist_all) {
   extern __shared__ float lds[];
   constexpr int NP = A::NP;
   // kRegs: samples and voxel queue in registers, LDS for the correction pairs only -- the form launched as one-wave
@@ -380,6 +386,10 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
   //      kRegs:      [kHistDoubles][kWg] double solver history, nothing else (samples and queue are in registers)
   double* hist = reinterpret_cast<double*>(lds + (kWaveWg ? 0 : ((P.n_te * kStride + 1) & ~1))) + threadIdx.x;
   uint32_t* queue = reinterpret_cast<uint32_t*>(hist - threadIdx.x + A::kHistDoubles * kWg) + wave * kQueueCap;
+  // A::kGlobalPart: this wave's M x 64 doubles of the pairs' global part ([ring slot][lane], 5 KiB, L2-resident)
+  double* ghist = nullptr;
+  if constexpr (A::kGlobalPart)
+    ghist = ghist_all + ((size_t)blockIdx.x * (kWg / 64) + wave) * (A::Solver::M * 64) + lane;
   uint32_t qv = 0;  // kWaveWg: lane r holds the r-th waiting voxel of the chunk last taken
   const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const EchoView y{col, kStride};
@@ -612,7 +622,7 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
             c.trace_n = m.trace_len + v;
             *c.trace_n = 0;
           }
-          A::init(s, c, box_x0, lb, ub, hist, kWg);
+          A::init(s, c, box_x0, lb, ub, hist, kWg, ghist);
 #if defined(T2_PHASE_STAMPS)
           if constexpr (A::kSplit) s.diag = diag;
 #endif
@@ -677,8 +687,8 @@ __global__ __launch_bounds__(kWg, kWavesPerSimd) void fit_persistent_kernel(cons
                                                                     const float* __restrict__ echoes, int layout,
                                                                     const uint8_t* __restrict__ mask, int64_t n_vox,
                                                                     DevMaps m, unsigned long long* next_chunk, int refill_min,
-                                                                    int park_min, int take) {
-  persistent_fit<A, kChunk, kTrace, kExtras, kWg, kRegs>(P, echoes, layout, mask, n_vox, m, next_chunk, refill_min, park_min, take);
+                                                                    int park_min, int take, double* ghist) {
+  persistent_fit<A, kChunk, kTrace, kExtras, kWg, kRegs>(P, echoes, layout, mask, n_vox, m, next_chunk, refill_min, park_min, take, ghist);
 }
 
 // Residual map (utils/t2map_utils.py:62-89) and optional R^2 from float32 maps already on the device.
@@ -891,20 +901,24 @@ hipError_t launch_persistent(unsigned grid, size_t lds_samples, hipStream_t st, 
   if constexpr (kLargeOnly && A::kHistDoubles > 0 && A::kWaveWgOk) {
     // One-wave workgroups.  The lane's correction pairs (400 B with three parameters, 240 B with two: s is kept as a
     // direction, t2fit_lbfgsb.h load_s) cap a CU's 160 KiB of LDS at 409 lanes: four waves as one 256-lane workgroup,
-    // but SIX as one-wave workgroups (eight with two parameters) -- the lane fits 256 registers, so two SIMDs (all
-    // four) of each CU then interleave two waves.  Nothing but the pairs is in LDS: the samples are in registers
-    // (echo-count specialisation), the voxel queue too.
+    // six as one-wave workgroups (round 2), and EIGHT -- two on every SIMD, what the lane's 256 registers allow -- once
+    // one of a pair's five numbers lives in global memory instead (A::WaveWg, Lbfgsb<.., GSPLIT>: 320 B per lane, 16 of
+    // a CU's 128 LDS pieces per wave; the 10 MiB of the global part stay in L2).  Measured on one box, maps identical
+    // bit for bit: 256^3 x 8 TE 13.62 -> 12.02 ms; with the split ring but capped at six waves 14.05 (the global
+    // accesses cost 3 %), at seven 12.96 (profiles/r03_exp3_eight_waves.txt).  Nothing but the pairs is in LDS: the
+    // samples are in registers (echo-count specialisation), the voxel queue too.
     if (g_wave_wg) {
       // (T2FIT_WAVE_WG=2 / 3: the same register-queue code in workgroups of 256 / 128 lanes -- diagnostic builds only)
-      constexpr int kHint = A::kWaveWgHint;  // waves per SIMD the register allocator is held to
-      auto k64 = extras ? fit_persistent_kernel<A, kChunkSmall, false, kHint, true, 64, true>
-                        : fit_persistent_kernel<A, kChunkSmall, false, kHint, false, 64, true>;
+      using AW = typename A::WaveWg;  // three parameters: one number of every pair in global memory, 320 B of LDS per lane
+      constexpr int kHint = AW::kWaveWgHint;  // waves per SIMD the register allocator is held to
+      auto k64 = extras ? fit_persistent_kernel<AW, kChunkSmall, false, kHint, true, 64, true>
+                        : fit_persistent_kernel<AW, kChunkSmall, false, kHint, false, 64, true>;
       unsigned wg = 64;
 #if defined(T2_WG_SHAPE_DIAG)
-      if (g_wave_wg == 2) { k64 = fit_persistent_kernel<A, kChunkSmall, false, 1, false, 256, true>; wg = 256; }
-      if (g_wave_wg == 3) { k64 = fit_persistent_kernel<A, kChunkSmall, false, 1, false, 128, true>; wg = 128; }
+      if (g_wave_wg == 2) { k64 = fit_persistent_kernel<AW, kChunkSmall, false, 1, false, 256, true>; wg = 256; }
+      if (g_wave_wg == 3) { k64 = fit_persistent_kernel<AW, kChunkSmall, false, 1, false, 128, true>; wg = 128; }
 #endif
-      size_t lds64 = (size_t)A::kHistDoubles * wg * sizeof(double);
+      size_t lds64 = (size_t)AW::kHistDoubles * wg * sizeof(double);
       // (LDS is handed out in 1280-byte pieces, 128 to a CU: measured with tools/diag/wave_placement_probe.hip, five
       // workgroups of 32000 bytes are resident together, of 32768 four)
       unsigned per_cu = (unsigned)std::min<size_t>(wg == 64 ? 4 * kHint : 512 / wg, 128 / ((lds64 + 1279) / 1280));
@@ -919,10 +933,21 @@ hipError_t launch_persistent(unsigned grid, size_t lds_samples, hipStream_t st, 
       if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
       if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
       grid = std::min<unsigned>(grid, (unsigned)cus);  // every wave that fits is resident; more would only start to leave
-      hipLaunchKernelGGL(k64, dim3(grid * per_cu), dim3(wg), lds64, st, P, echoes, layout, mask, n_vox, dm, counter,
-                         g_refill_min > 0 ? g_refill_min : A::kRefillMin, g_park_min,
-                         g_take > 0 ? g_take : 2);
-      return hipGetLastError();
+      const unsigned n_wg = grid * per_cu;
+      double* ghist = nullptr;
+      if constexpr (AW::kGlobalPart) {  // M x 64 doubles per wave (5 KiB; 10 MiB for the whole chip: it lives in L2)
+        e = hipMallocAsync((void**)&ghist, (size_t)n_wg * (wg / 64) * AW::Solver::M * 64 * sizeof(double), st);
+        if (e != hipSuccess) return e;
+      }
+      hipLaunchKernelGGL(k64, dim3(n_wg), dim3(wg), lds64, st, P, echoes, layout, mask, n_vox, dm, counter,
+                         g_refill_min > 0 ? g_refill_min : AW::kRefillMin, g_park_min,
+                         g_take > 0 ? g_take : 2, ghist);
+      e = hipGetLastError();
+      if (ghist) {
+        const hipError_t e2 = hipFreeAsync(ghist, st);
+        if (e == hipSuccess) e = e2;
+      }
+      return e;
     }
   }
 #endif
@@ -947,7 +972,7 @@ hipError_t launch_persistent(unsigned grid, size_t lds_samples, hipStream_t st, 
                                      (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox, dm, counter,
-                     g_refill_min > 0 ? g_refill_min : A::kRefillMin, g_park_min, 1);
+                     g_refill_min > 0 ? g_refill_min : A::kRefillMin, g_park_min, 1, (double*)nullptr);
   return hipGetLastError();
   }
 }

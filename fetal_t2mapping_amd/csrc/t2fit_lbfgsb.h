@@ -375,12 +375,18 @@ template <int NTE> struct RowSums4 {
 // NTE > 0 fixes the number of echoes at compile time (the kernels instantiate the common train lengths): the
 // evaluation then is one straight-line block -- no per-echo `i < n` tests between the echoes, so their
 // exp / sqrt chains interleave -- and only the summation order that numpy uses for that length is carried.
-template <int MODEL, int NTE = 0>
+// GSPLIT (three parameters only): the last ratio of every pair's s lives in a second array (`ghist`, global memory in
+// the kernels) instead of the ring in LDS.  Four instead of five doubles per pair are then in LDS, 320 instead of 400
+// bytes per lane, and 160 KiB hold the rings of EIGHT one-wave workgroups instead of six: every SIMD of a CU
+// interleaves two waves.  Where a number is kept does not change it: results are the same bit for bit.
+template <int MODEL, int NTE = 0, bool GSPLIT = false>
 struct Lbfgsb {
   static constexpr int N = MODEL == T2FIT_MODEL_GAUSSIAN ? 2 : 3;
   static constexpr int kNte = NTE;
   static constexpr int M = 10;
-  static constexpr int PAIR = 2 * N - 1;  // doubles per correction pair in the ring (see load_s / store_s)
+  static constexpr int PAIR = 2 * N - 1;  // doubles per correction pair (see load_s / store_s)
+  static constexpr bool kSplit = GSPLIT && N == 3;
+  static constexpr int PAIR_L = kSplit ? PAIR - 1 : PAIR;  // of which in the ring `hist`
 
   double lb[N], ub[N];              // box
   double x[N], g[N], f;             // current evaluation point, objective, FD gradient
@@ -391,7 +397,8 @@ struct Lbfgsb {
   // y / sqrt(y's): see store_s), element e of slot q at hist[(q*PAIR + e) * hstride].  In the kernel that is LDS (one
   // column per lane, 400 B per lane for n = 3), which is what keeps the solver state within the VGPR budget.
   double* hist;
-  int hstride, head;
+  double* ghist;  // kSplit: element q * gstride holds the last ratio of the pair in ring slot q
+  int hstride, gstride, head;
   int iwhere[N];
   int col, nit, nfev, ifun;
   uint8_t status;
@@ -563,8 +570,13 @@ struct Lbfgsb {
   // that is zero (the variable sat at its bound during the step) or vanishingly small is replaced by
   // +-2^-400 max|s_i|: the direction moves by 2^-400, the ratios stay below 2^400 and their squares times B finite.
   T2_HD int slot_of(int p) const { return (head + p) % M; }
-  T2_HD double& hratio(int q, int e) const { return hist[(q * PAIR + e) * hstride]; }
-  T2_HD double& hy(int q, int i) const { return hist[(q * PAIR + (N - 1) + i) * hstride]; }
+  T2_HD double& hratio(int q, int e) const {
+    if constexpr (kSplit) {
+      if (e == N - 2) return ghist[q * gstride];
+    }
+    return hist[(q * PAIR_L + e) * hstride];
+  }
+  T2_HD double& hy(int q, int i) const { return hist[(q * PAIR_L + (kSplit ? N - 2 : N - 1) + i) * hstride]; }
   T2_HD void load_s(int q, double* sv) const {  // as a vector (tests; build_b() reads the ratios directly)
     sv[0] = 1.0;
     T2_UNROLL
@@ -852,10 +864,13 @@ struct Lbfgsb {
   }
 
   // Start a fit: x = x0 clipped into the box (scipy), empty memory.  Next: eval(), then advance().
-  // `hist_` must hold 2*M*N doubles at stride `hstride_`.
-  T2_HD void init(const double* x0_, const double* lb_, const double* ub_, double* hist_, int hstride_) {
+  // `hist_` must hold M * PAIR_L doubles at stride `hstride_` (kSplit: and `ghist_` M doubles at stride `gstride_`).
+  T2_HD void init(const double* x0_, const double* lb_, const double* ub_, double* hist_, int hstride_,
+                  double* ghist_ = nullptr, int gstride_ = 0) {
     hist = hist_;
     hstride = hstride_;
+    ghist = ghist_;
+    gstride = gstride_;
     head = 0;
     T2_UNROLL
     for (int i = 0; i < N; ++i) {
