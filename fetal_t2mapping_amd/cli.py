@@ -5,8 +5,9 @@
 
 --gpus N (N > 1) starts one process per GPU (torch.distributed.run, RCCL) before anything touches a GPU: with at
 least N subjects in the CSVs each rank streams its own subjects (dist.subjects_of_rank: nothing is exchanged,
-BASELINE.json config 5); with fewer, every volume is cut over the ranks in balanced chunks and the four maps are
-all-gathered (dist.take_cyclic / gather_maps_cyclic, config 4); rank 0 writes the files of a shared volume.
+BASELINE.json config 5); with fewer, every volume is shared: each rank decodes 1/N of its echo files, one all-to-all
+hands every rank all echoes of its balanced share of the voxels, the maps (and the per-voxel status) are all-gathered
+(dist.exchange_echo_shares / gather_maps_cyclic, config 4); rank 0 writes the files of a shared volume.
 
 Same flags, metadata CSVs, input/output file names and maps as the reference
 (run_t2mapping.py:483-576, utils/metadata_utils.py, utils/qmri_utils.py:13-33,
@@ -73,11 +74,36 @@ def _pinned_stack(recon_paths):
         return None
 
 
+DECODED = {"echo": 0, "mask": 0}  # volume files this process has decoded (the shared-volume tests assert 1/G of them)
+
+
+def _read_geometry(sitk, path):
+    """Spacing / origin / direction of the image at `path` (an object with the three Get* methods) without decoding the
+    voxels where the reader can: the maps carry the geometry of the LAST echo's image (run_t2mapping.py:377 /
+    utils/t2map_utils.py:22-24), which the rank that writes them may not have decoded."""
+    from . import nifti
+
+    if sitk is nifti:
+        return nifti.ReadGeometry(path)
+    if hasattr(sitk, "ImageFileReader"):  # SimpleITK: header only
+        r = sitk.ImageFileReader()
+        r.SetFileName(path)
+        r.ReadImageInformation()
+        return nifti.Image(np.zeros((0, 0, 0), np.float32), r.GetSpacing(), r.GetOrigin(), r.GetDirection())
+    return sitk.ReadImage(path)
+
+
 def _read_subject(sitk, recon_paths, mask_paths, label_path):
     """All volumes of one (sub, ses): echoes, masks, optional vial labels, and the last recon image (its
     geometry goes onto the maps, run_t2mapping.py:377 / utils/t2map_utils.py:22-24).  With the native
     reader the files are decoded concurrently, the echoes straight into one float32 (nTE,Z,Y,X) block."""
     from . import nifti
+
+    DECODED["echo"] += len(recon_paths)
+    DECODED["mask"] += len(mask_paths)
+    if not recon_paths:  # a rank of a shared volume with more ranks than echoes
+        label = sitk.GetArrayFromImage(sitk.ReadImage(label_path)) if label_path else None
+        return [], [], label, None
 
     if sitk is nifti:
         from concurrent.futures import ThreadPoolExecutor
@@ -185,7 +211,7 @@ def save_phantom_csv(t2_map, k_map, sigma_map, label, id, gt, bids_path, acq, di
 
 
 # ---- driver ------------------------------------------------------------------------------------
-def _fit_subject(vols, masks, keep, te_eff, fit, fit_params, prior, norm, solver, precision, device):
+def _fit_subject(vols, masks, keep, te_eff, fit, fit_params, prior, norm, solver, precision, device, numpy_legacy=False):
     """One (sub, ses): union mask + flat indices on the device (bit-identical to
     run_t2mapping.py:383-384,412,421), fit, maps back to the host as (Z,Y,X) float32."""
     import torch
@@ -196,7 +222,7 @@ def _fit_subject(vols, masks, keep, te_eff, fit, fit_params, prior, norm, solver
     shape = mask.shape
     mask_d = torch.from_numpy(mask.astype(np.uint8).reshape(-1)).to(echoes.device)
     maps = t2map.fit_volume(echoes.reshape((len(vols),) + shape), mask_d, te_eff, fit, fit_params, prior=prior,
-                            norm=norm, solver=solver, precision=precision, extras=True)
+                            norm=norm, solver=solver, precision=precision, extras=True, numpy_legacy=numpy_legacy)
     torch.cuda.synchronize()
     out = tuple(getattr(maps, n).cpu().numpy() for n in ("t2", "k", "sigma", "res"))
     extras = {"nit": maps.nit.cpu().numpy(), "fun": maps.fun.cpu().numpy()}  # what the convergence figures need
@@ -208,9 +234,10 @@ def _dist_env():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def _fit_share(e_share, m_share, te_eff, fit, fit_params, prior, norm, solver, precision, device):
-    """This rank's share of a volume ((nTE, per) float32, (per,) uint8, host arrays) -> packed maps [4, per] on the GPU
-    (t2, k, sigma, res).  The only function of the sharded path that touches the device."""
+def _fit_share(e_share, m_share, te_eff, fit, fit_params, prior, norm, solver, precision, device, numpy_legacy=False):
+    """This rank's share of a volume ((nTE, per) float32 and (per,) uint8: CUDA tensors, or host arrays that are sent
+    first) -> ``(packed [6, per] float32 on the GPU: t2, k, sigma, res, fun, nit (int32 bit patterns), status (per,)
+    uint8)``.  The only function of the shared-volume path that calls the fit."""
     import ctypes as C
 
     import torch
@@ -221,56 +248,106 @@ def _fit_share(e_share, m_share, te_eff, fit, fit_params, prior, norm, solver, p
     lib = require_gpu()
     dev = torch.device("cuda", device)
     with torch.cuda.device(dev):
-        e_d, m_d = torch.from_numpy(e_share).to(dev), torch.from_numpy(m_share).to(dev)
-        per = e_share.shape[1]
-        packed = torch.empty((4, per), dtype=torch.float32, device=dev)
-        cfg = t2map.make_config(fit, fit_params, te_eff, prior, norm, solver, precision)
+        e_d = (e_share if torch.is_tensor(e_share) else torch.from_numpy(e_share)).to(dev, non_blocking=True).contiguous()
+        m_d = (m_share if torch.is_tensor(m_share) else torch.from_numpy(m_share)).to(dev, non_blocking=True).contiguous()
+        per = e_d.shape[1]
+        packed = torch.empty((6, per), dtype=torch.float32, device=dev)
+        status = torch.empty(per, dtype=torch.uint8, device=dev)
+        cfg = t2map.make_config(fit, fit_params, te_eff, prior, norm, solver, precision, numpy_legacy)
         maps = _abi.T2FitMaps()
-        maps.t2, maps.k, maps.sigma, maps.res = (packed[j].data_ptr() for j in range(4))
+        maps.t2, maps.k, maps.sigma, maps.res, maps.fun, maps.nit = (packed[j].data_ptr() for j in range(6))
+        maps.status = status.data_ptr()
         check(lib.t2fit_volume_dev(C.byref(cfg), e_d.data_ptr(), _abi.LAYOUT_TE_MAJOR, m_d.data_ptr(), per, C.byref(maps),
                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         torch.cuda.synchronize()
-    return packed
+    return packed, status
 
 
-def _fit_subject_sharded(vols, masks, keep, te_eff, fit, fit_params, prior, norm, solver, precision, device):
-    """One (sub, ses) over all ranks (BASELINE.json config 4): union mask on the host (run_t2mapping.py:383-384), this
-    rank's balanced share of the voxels to its GPU, fit, one all-gather of the four maps.  Every rank returns the
-    complete maps; same return shape as _fit_subject (status and extras are not gathered: None)."""
+def _fit_subject_shared(sitk, recon_paths, mask_paths, label_path, fast, te_eff, fit, fit_params, prior, norm, solver,
+                        precision, device, numpy_legacy=False):
+    """One (sub, ses) over all ranks (BASELINE.json config 4, or any run with fewer subjects than ranks).
+
+    Rank r decodes the echo files r, r + G, ... and their mask files only; the union mask (run_t2mapping.py:383-384) is
+    an all-reduce of the partial unions; one all-to-all hands every rank all echoes of its balanced share of the voxels
+    (dist.exchange_echo_shares); every rank fits its share; one all-gather assembles t2 / k / sigma / res / fun / nit on
+    every rank and a second, a quarter its size, the status bytes -- so the `FAIL : Optimization failed` count
+    (run_t2mapping.py:298-303) and the convergence figures work here as in the single-process run.
+    Returns ``(mask, (t2, k, sigma, res), status, extras, recon_img, label, my_vols)``."""
+    import torch
     import torch.distributed as dist
 
     from . import dist as t2dist
 
     rank, world = dist.get_rank(), dist.get_world_size()
-    mask = np.zeros(np.asarray(masks[0]).shape, bool)
+    n_te = len(recon_paths)
+    mine = t2dist.echoes_of_rank(n_te, rank, world)
+    vols, masks, label, _ = _read_subject(sitk, [recon_paths[i] for i in mine], [mask_paths[i] for i in mine], label_path)
+    recon_img = _read_geometry(sitk, recon_paths[-1])
+    # shape of the volume: from an echo this rank decoded, else from the label, else from a peer (broadcast)
+    shape = [tuple(np.asarray(vols[0]).shape) if vols else None]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, shape[0])
+        shape[0] = next(sh for sh in gathered if sh is not None)
+    shape = tuple(shape[0])
+    n = int(np.prod(shape))
+    on_gpu = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", device) if on_gpu else torch.device("cpu")
+    part = np.zeros(n, np.uint8)
     for m in masks:
-        mask |= np.asarray(m) != 0
-    if keep is not None:
-        mask &= keep
-    shape = mask.shape
-    n = mask.size
-    e = np.empty((len(vols), t2dist.cyclic_len(n, world)), np.float32)
-    msh = np.zeros(e.shape[1], np.uint8)
-    flat_mask = mask.reshape(-1)
-    for j, c in enumerate(t2dist.cyclic_chunks(n, rank, world)):  # chunk by chunk: contiguous runs, only this rank's
-        lo = int(c) * t2dist.CHUNK
-        if lo >= n:
-            e[:, j * t2dist.CHUNK:] = 0.0
-            break
-        hi = min(lo + t2dist.CHUNK, n)
-        for i, v in enumerate(vols):
-            e[i, j * t2dist.CHUNK: j * t2dist.CHUNK + hi - lo] = np.asarray(v).reshape(-1)[lo:hi]
-        e[:, j * t2dist.CHUNK + hi - lo: (j + 1) * t2dist.CHUNK] = 0.0
-        msh[j * t2dist.CHUNK: j * t2dist.CHUNK + hi - lo] = flat_mask[lo:hi]
-    packed = _fit_share(e, msh, te_eff, fit, fit_params, prior, norm, solver, precision, device)
+        part |= (np.asarray(m).reshape(-1) != 0).astype(np.uint8)
+    if vols:
+        # (the native reader decodes into one page-locked block: sent as it lies, no staging copy)
+        host = _one_block(vols) if _is_one_block(vols) else np.stack([np.asarray(v, np.float32).reshape(-1) for v in vols])
+        mine_t = torch.from_numpy(host).to(dev, non_blocking=True)
+    else:
+        mine_t = torch.zeros((0, n), dtype=torch.float32, device=dev)
+    mask_t = t2dist.union_mask_over_ranks(torch.from_numpy(part).to(dev))
+    if fast and label is not None:  # run_t2mapping.py:394-400: fit the labelled vials only
+        mask_t = mask_t * torch.from_numpy((np.asarray(label).reshape(-1) != 0).astype(np.uint8)).to(dev)
+    e_share = t2dist.exchange_echo_shares(mine_t, n_te, n)
+    m_share = t2dist.share_of(mask_t, n, rank, world)
+    fitted = _fit_share(e_share, m_share, te_eff, fit, fit_params, prior, norm, solver, precision, device,
+                        **({"numpy_legacy": True} if numpy_legacy else {}))
+    packed, st_share = fitted if isinstance(fitted, tuple) else (fitted, None)
+    if not on_gpu:
+        packed = packed.cpu()
     full = t2dist.gather_maps_cyclic(packed, n).cpu().numpy()
+    mask = mask_t.cpu().numpy().astype(bool).reshape(shape)
     out = tuple(np.ascontiguousarray(full[j]).reshape(shape) for j in range(4))
-    status = np.where(flat_mask, np.where(np.isnan(full[0]), 4, 1), 0).astype(np.uint8).reshape(shape)  # NaN maps = infeasible bounds
-    return mask, out, status
+    if st_share is not None:
+        status = t2dist.gather_maps_cyclic(st_share.view(1, -1) if on_gpu else st_share.cpu().view(1, -1), n)[0].cpu().numpy().reshape(shape)
+    else:  # a fit stand-in without a status row (tests): NaN maps = infeasible bounds, everything else converged
+        status = np.where(mask, np.where(np.isnan(out[0]), 4, 1), 0).astype(np.uint8)
+    extras = None
+    if full.shape[0] >= 6:
+        extras = {"fun": np.ascontiguousarray(full[4]).reshape(shape),
+                  "nit": np.ascontiguousarray(full[5]).view(np.int32).reshape(shape)}
+    my_vols = {i: v for i, v in zip(mine, vols)}
+    return mask, out, status, extras, recon_img, label, my_vols
+
+
+def _is_one_block(vols):
+    """True when the echo volumes are consecutive views of one C-contiguous float32 block (nifti.read_stack)."""
+    try:
+        a0 = vols[0]
+        if a0.dtype != np.float32 or not a0.flags.c_contiguous:
+            return False
+        step = a0.nbytes
+        base = a0.ctypes.data
+        return all(v.dtype == np.float32 and v.flags.c_contiguous and v.ctypes.data == base + j * step for j, v in enumerate(vols))
+    except AttributeError:
+        return False
+
+
+def _one_block(vols):
+    """The (n, N) float32 view over the block `_is_one_block` recognised: no copy."""
+    n = vols[0].size
+    return np.lib.stride_tricks.as_strided(vols[0].reshape(-1), shape=(len(vols), n), strides=(vols[0].nbytes, 4))
 
 
 def process_t2maps(metadata, bids_path, TEs, fit, fit_params, phantom, low_field, prior, fast, norm, sim,
-                   solver="lbfgsb", precision="f64", device=0, plots=False, plot_seed=None):
+                   solver="lbfgsb", precision="f64", device=0, plots=False, plot_seed=None, numpy_legacy=False):
     """run_t2mapping.py:333-479 with the voxel loop on the GPU.  ``plots``: also write the reference's
     convergence-study figures (:465-468) under <prj>/ada/convergence_analysis."""
     sitk = _sitk()
@@ -284,7 +361,6 @@ def process_t2maps(metadata, bids_path, TEs, fit, fit_params, phantom, low_field
     mine = set(subjects if (world == 1 or share_volumes) else
                [subjects[i] for i in dist_subjects_of_rank(len(subjects), rank, world)])
     writer = (rank == 0) or not share_volumes
-    fit_one = _fit_subject_sharded if share_volumes else _fit_subject
     for prj, prj_md in metadata.groupby("prj"):
         for (sub, ses), sub_md in prj_md.groupby(["sub", "ses"]):
             if (prj, sub, ses) not in mine:
@@ -300,14 +376,25 @@ def process_t2maps(metadata, bids_path, TEs, fit, fit_params, phantom, low_field
             if not np.array_equal(te_eff, TEs):
                 print(f"Warning: one or more TEs selected to fit is missing for {sub}_{ses}. T2 fit is skipped.")
                 continue
-            vols, masks, label, recon_img = _read_subject(sitk, recon_paths, mask_paths, label_path)
-            keep = (label != 0) if (phantom and fast) else None  # :394-400
             print(f"T2 Mapping: {prj}_{sub}_{ses}")
             print(f"TEeffs: {te_eff}")
             print(f"Fitting using {fit} model ... ")
-            t0 = time.time()
-            fitted = fit_one(vols, masks, keep, te_eff, fit, fit_params, prior, norm, solver, precision, device)
-            mask, (t2_map, k_map, sigma_map, res_map), status = fitted[:3]
+            my_vols = None
+            if share_volumes:  # every rank decodes 1/G of the echo files; shares are swapped on the way to the fit
+                t0 = time.time()
+                mask, maps4, status, extras, recon_img, label, my_vols = _fit_subject_shared(
+                    sitk, recon_paths, mask_paths, label_path, phantom and fast, te_eff, fit, fit_params, prior, norm, solver,
+                    precision, device, numpy_legacy)
+                vols = None
+            else:
+                vols, masks, label, recon_img = _read_subject(sitk, recon_paths, mask_paths, label_path)
+                keep = (label != 0) if (phantom and fast) else None  # :394-400
+                t0 = time.time()
+                fitted = _fit_subject(vols, masks, keep, te_eff, fit, fit_params, prior, norm, solver, precision, device,
+                                      **({"numpy_legacy": True} if numpy_legacy else {}))
+                mask, maps4, status = fitted[:3]
+                extras = fitted[3] if len(fitted) > 3 else None
+            t2_map, k_map, sigma_map, res_map = maps4
             print(f"Dimensions of the t2w images: {mask.shape + (te_eff.size,)} (z,y,x,necho)")
             print(f"Mask Dimension: {mask.shape} -  Number of voxels inside mask: {int(np.sum(mask))}")
             if np.any(status == 4):  # scipy raises here and the reference's pool.map aborts the run
@@ -316,15 +403,33 @@ def process_t2maps(metadata, bids_path, TEs, fit, fit_params, phantom, low_field
             if n_fail:
                 print(f"FAIL : Optimization failed for {n_fail} voxels")
             print(f"... done. Time to fit: {round(time.time() - t0, 4)} sec")
+            want_plots = plots and extras is not None and solver != "loglin"  # the closed form has no iterations to plot
+            picks = rows = None
+            if want_plots and share_volumes:
+                # the sampled voxels' rows come from the ranks that decoded each echo: rank 0 draws the sample (the
+                # reference's is unseeded), everybody contributes its echoes' columns
+                import torch
+                import torch.distributed as dist
+
+                from . import convergence
+                from . import dist as t2dist
+
+                mask_idx = np.flatnonzero(mask.reshape(-1))
+                box = [convergence.pick_voxels(len(mask_idx), plot_seed) if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                picks = box[0]
+                dev = torch.device("cuda", device) if dist.get_backend() == "nccl" else torch.device("cpu")
+                rows = t2dist.rows_from_owners(mask_idx[list(picks[0]) + list(picks[1])], my_vols, len(te_eff), dev)
             if not writer:
                 continue
-            if plots and len(fitted) > 3 and solver != "loglin":  # the closed form has no iterations to plot
+            if want_plots:
                 from . import convergence
 
                 convergence.convergence_study(convergence.set_ada_path(bids_path, prj), vols,
-                                              np.flatnonzero(mask.reshape(-1)), t2_map, fitted[3]["nit"], fitted[3]["fun"],
+                                              np.flatnonzero(mask.reshape(-1)), t2_map, extras["nit"], extras["fun"],
                                               te_eff, fit, fit_params, prior, norm, sub, ses, sim, solver=solver,
-                                              precision=precision, device=device, seed=plot_seed)
+                                              precision=precision, device=device, seed=plot_seed, picks=picks, rows=rows,
+                                              numpy_legacy=numpy_legacy)
             save_nifti_maps(t2_map, k_map, sigma_map, res_map, t2map_dirname, recon_img, bids_path, acq, sim, fit)
             if phantom:
                 # the reference unpacks (gt, id) as id, gt (run_t2mapping.py:27 vs :478), which swaps the
@@ -374,6 +479,9 @@ def parse_arguments(argv=None):
     p.add_argument("--gpus", type=int, default=1,
                    help="GPUs of this node to use: N > 1 starts one process per GPU (torch.distributed.run, RCCL); subjects "
                         "are dealt to the ranks, or, with fewer subjects than ranks, every volume is cut over the ranks")
+    p.add_argument("--numpy_legacy", action="store_true",
+                   help="reproduce the reference as it runs under the numpy < 2 it freezes (requirements_frozen.txt:103): "
+                        "float32 log term of the rician objective, float32 prediction of the residual map; default: numpy >= 2")
     p.add_argument("--plots", action="store_true",
                    help="write the reference's convergence-study PNGs (run_t2mapping.py:465-468) under "
                         "<prj>/ada/convergence_analysis; off by default, the reference always draws them")
@@ -432,7 +540,7 @@ def main(argv=None):
     try:
         process_t2maps(metadata, bids_path, TEs, fit, fit_params, phantom, low_field, not args.no_prior, fast,
                        bool(args.norm), args.sim, solver=args.solver, precision=args.precision, device=args.device,
-                       plots=args.plots, plot_seed=args.plot_seed)
+                       plots=args.plots, plot_seed=args.plot_seed, numpy_legacy=args.numpy_legacy)
     finally:
         if world > 1:
             import torch.distributed as dist

@@ -82,30 +82,41 @@ def _scatter(path, nit, fun, t2_values):
     plt.close(fig)
 
 
-def convergence_study(ada_path: str, echo_vols: Sequence[np.ndarray], mask_indices: np.ndarray, t2_map: np.ndarray,
+def pick_voxels(n_masked: int, seed: Optional[int] = None):
+    """The two samples of the figures, as positions in ``mask_indices``: (50 for the objective curves, 20 for the step
+    lengths), drawn like the reference draws them (two ``random.sample`` calls)."""
+    rng = random.Random(seed)
+    return sample_voxels(n_masked, N_CURVES_OBJECTIVE, rng), sample_voxels(n_masked, N_CURVES_STEP, rng)
+
+
+def convergence_study(ada_path: str, echo_vols: Optional[Sequence[np.ndarray]], mask_indices: np.ndarray, t2_map: np.ndarray,
                       nit_map: np.ndarray, fun_map: np.ndarray, TEeffs, fit: str, fit_params: dict, prior: bool, norm: bool,
                       sub: str, ses: str, sim, *, solver: str = "lbfgsb", precision: str = "f64", device: int = 0,
-                      seed: Optional[int] = None, trace_cap: int = 256) -> list:
+                      seed: Optional[int] = None, trace_cap: int = 256, picks=None, rows: Optional[np.ndarray] = None,
+                      numpy_legacy: bool = False) -> list:
     """Write the three figures; returns their paths.
 
     ``echo_vols``: the nTE volumes (only the sampled voxels' rows are gathered, the (N, nTE) stack of
     run_t2mapping.py:411 is not built); ``mask_indices``: flat indices of the fitted voxels;
-    ``t2_map`` / ``nit_map`` / ``fun_map``: maps of the finished fit (N elements each).
+    ``t2_map`` / ``nit_map`` / ``fun_map``: maps of the finished fit (N elements each).  A caller that does not hold
+    every echo (one volume shared by several ranks) draws the sample itself (``pick_voxels``) and hands in ``picks``
+    and the sampled voxels' ``rows`` (len(picks[0]) + len(picks[1]), nTE) instead of ``echo_vols``.
     """
     from . import t2map
 
-    rng = random.Random(seed)
     mask_indices = np.asarray(mask_indices, np.int64)
     t2_map, nit_map, fun_map = (np.asarray(a).reshape(-1) for a in (t2_map, nit_map, fun_map))
-    pick_f = sample_voxels(len(mask_indices), N_CURVES_OBJECTIVE, rng)
-    pick_s = sample_voxels(len(mask_indices), N_CURVES_STEP, rng)
-    picks = pick_f + pick_s
+    pick_f, pick_s = picks if picks is not None else pick_voxels(len(mask_indices), seed)
+    picks = list(pick_f) + list(pick_s)
     infos = []
     if picks:
         sel = mask_indices[picks]
-        rows = np.stack([np.asarray(v).reshape(-1)[sel] for v in echo_vols], axis=1).astype(np.float32)
+        if rows is None:
+            rows = np.stack([np.asarray(v).reshape(-1)[sel] for v in echo_vols], axis=1).astype(np.float32)
+        rows = np.ascontiguousarray(rows, np.float32)
         infos = t2map.fit_voxels_trace(np.arange(len(sel)), fit, fit_params, TEeffs, rows, prior, norm,
-                                       trace_cap=trace_cap, solver=solver, precision=precision, device=device)[5]
+                                       trace_cap=trace_cap, solver=solver, precision=precision, device=device,
+                                       numpy_legacy=numpy_legacy)[5]
     t2_of = lambda sel: [float(t2_map[mask_indices[i]]) for i in sel]  # noqa: E731
     out = [os.path.join(ada_path, f"convergence_20_random_voxels_colored_by_t2_{sub}_{ses}_sim-{sim}_{fit}.png"),
            os.path.join(ada_path, f"step_size_convergence_20_random_voxels_colored_by_t2_{sub}_{ses}_sim-{sim}.png"),

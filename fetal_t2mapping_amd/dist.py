@@ -116,15 +116,15 @@ def take_cyclic(echoes: np.ndarray, mask: Optional[np.ndarray], rank: int, world
 
 
 def gather_maps_cyclic(packed_local, n_vox: int, chunk: int = CHUNK, group=None):
-    """All-gather of the per-rank packed maps ``[N_MAPS, per]`` of the cyclic partition into ``[N_MAPS, n_vox]`` in
-    voxel order on every rank: one collective, then one gather of whole chunks (chunk ``g*world + j`` sits in slot
-    ``g`` of rank ``(j + rotation(g)) % world``)."""
+    """All-gather of the per-rank packed maps ``[R, per]`` of the cyclic partition (R = N_MAPS, or more rows when
+    per-voxel extras travel along; any dtype) into ``[R, n_vox]`` in voxel order on every rank: one collective, then
+    one gather of whole chunks (chunk ``g*world + j`` sits in slot ``g`` of rank ``(j + rotation(g)) % world``)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    per = packed_local.shape[1]
-    assert packed_local.shape[0] == N_MAPS and per == cyclic_len(n_vox, world, chunk)
+    N_MAPS, per = packed_local.shape  # noqa: N806  (rows of this call)
+    assert per == cyclic_len(n_vox, world, chunk)
     packed_local = packed_local.contiguous()
     gathered = torch.empty((world, N_MAPS, per), dtype=packed_local.dtype, device=packed_local.device)
     dist.all_gather_into_tensor(gathered.view(-1), packed_local.view(-1), group=group)
@@ -137,14 +137,91 @@ def gather_maps_cyclic(packed_local, n_vox: int, chunk: int = CHUNK, group=None)
     return by_chunk.index_select(1, src_t).reshape(N_MAPS, world * per)[:, :n_vox]
 
 
+# ---- one volume, G ranks, each rank decodes only some of the echo FILES ------------------------------------------------
+# The file edge dominates end to end (gzip decode of 8 x 256^3 float32 is seconds on a CPU, the fit
+# tens of milliseconds), so when one volume is shared by G ranks each rank decodes the echo files i = rank, rank + G, ...
+# only (config 4 on 8 GPUs: one 377 MB file instead of eight), and the ranks then swap voxel shares of their echoes with
+# ONE all-to-all (RCCL over xGMI: every rank sends each peer that peer's chunks of its echoes): afterwards every rank
+# holds all echoes of its own share of the voxels, which is what the fit needs.
+def echoes_of_rank(n_te: int, rank: int, world: int) -> list:
+    """Echo files rank ``rank`` decodes: i = rank, rank + world, ..."""
+    return list(range(rank, n_te, world))
+
+
+def exchange_echo_shares(mine, n_te: int, n_vox: int, chunk: int = CHUNK, group=None):
+    """``mine``: torch float32 ``[len(echoes_of_rank), n_vox]`` -- the whole volumes of the echoes this rank decoded, on
+    the device the backend moves (CUDA with RCCL, CPU with gloo).  Returns ``[n_te, per]``: every echo of this rank's
+    share of the voxels under the cyclic partition (``cyclic_index``; padding voxels are 0).  One ``all_to_all_single``."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    per = cyclic_len(n_vox, world, chunk)
+    slots = per // chunk
+    n_max = -(-n_te // world)                      # echoes per rank, padded to the same number everywhere
+    n_mine = len(echoes_of_rank(n_te, rank, world))
+    assert tuple(mine.shape) == (n_mine, n_vox), (tuple(mine.shape), n_mine, n_vox)
+    by_chunk = torch.zeros((n_mine, slots * world * chunk), dtype=torch.float32, device=mine.device)
+    by_chunk[:, :n_vox] = mine
+    by_chunk = by_chunk.view(n_mine, slots * world, chunk)
+    send = torch.zeros((world, n_max, slots, chunk), dtype=torch.float32, device=mine.device)
+    for d in range(world):                         # what peer d fits: its chunks of my echoes
+        sel = torch.from_numpy(cyclic_chunks(n_vox, d, world, chunk)).to(mine.device)
+        if n_mine:
+            send[d, :n_mine] = by_chunk.index_select(1, sel)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv.view(-1), send.view(-1), group=group)
+    out = torch.empty((n_te, per), dtype=torch.float32, device=mine.device)
+    for i in range(n_te):                          # echo i was decoded by rank i % world as its (i // world)-th
+        out[i] = recv[i % world, i // world].reshape(-1)
+    return out
+
+
+def union_mask_over_ranks(partial, group=None):
+    """run_t2mapping.py:383-384 when the mask files are spread over the ranks: ``partial`` = uint8 ``[n_vox]`` union of
+    the masks this rank read (zeros if it read none) -> the union over all ranks, on every rank (one all-reduce)."""
+    import torch.distributed as dist
+
+    dist.all_reduce(partial, op=dist.ReduceOp.MAX, group=group)
+    return partial
+
+
+def share_of(flat, n_vox: int, rank: int, world: int, chunk: int = CHUNK):
+    """This rank's share ``[per]`` of a full-volume vector ``[n_vox]`` (torch; padding = 0) under the cyclic partition."""
+    import torch
+
+    per = cyclic_len(n_vox, world, chunk)
+    padded = torch.zeros((per * world,), dtype=flat.dtype, device=flat.device)
+    padded[:n_vox] = flat
+    sel = torch.from_numpy(cyclic_chunks(n_vox, rank, world, chunk)).to(flat.device)
+    return padded.view(per * world // chunk, chunk).index_select(0, sel).reshape(-1)
+
+
+def rows_from_owners(sel, my_vols: dict, n_te: int, device, group=None):
+    """Samples of the voxels ``sel`` (flat indices) at every echo, assembled from the ranks that decoded each echo:
+    ``my_vols`` maps echo index -> this rank's host volume.  Returns float32 numpy ``(len(sel), n_te)`` on every rank
+    (one small all-reduce)."""
+    import torch
+    import torch.distributed as dist
+
+    rows = np.zeros((len(sel), n_te), np.float32)
+    for i, v in my_vols.items():
+        rows[:, i] = np.asarray(v).reshape(-1)[sel]
+    t = torch.from_numpy(rows).to(device)
+    dist.all_reduce(t, group=group)
+    return t.cpu().numpy()
+
+
 def fit_volume_sharded(echoes, mask, TEeffs, fit, fit_params, prior=True, norm=False, *, solver="lbfgsb",
                        precision="f64", group=None, partition="cyclic", chunk: int = CHUNK):
     """One volume over the GPUs of the group: each rank fits its share on its own GPU, one all-gather (RCCL over
     xGMI) assembles the four maps on every rank, and all ranks return the complete ``T2Maps`` (torch CUDA tensors
     shaped ``(Z, Y, X)``).
 
-    ``echoes``: host ``(nTE, Z, Y, X)`` float32 stack (numpy, or a memory map / pinned block: only this rank's share
-    is touched).  ``partition``: ``"cyclic"`` (chunks dealt round-robin: balanced whatever the mask looks like) or
+    ``echoes``: host ``(nTE, Z, Y, X)`` float32 stack, complete on every rank (numpy, a memory map or a pinned block;
+    this rank's share is copied out of it chunk by chunk).  A caller that starts from FILES should not decode them all
+    on every rank: ``cli._fit_subject_shared`` decodes 1/G of the echo files per rank and swaps shares with
+    ``exchange_echo_shares``.  ``partition``: ``"cyclic"`` (chunks dealt round-robin: balanced whatever the mask looks like) or
     ``"slab"`` (contiguous flat ranges, ``slab_range``: equals Z-slabs when Z divides by the group size)."""
     import ctypes as C
 

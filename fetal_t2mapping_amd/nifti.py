@@ -245,6 +245,18 @@ def ReadImage(path: str) -> Image:
     return Image(data.reshape(h.shape), h.spacing, h.origin, h.direction)
 
 
+def ReadGeometry(path: str) -> Image:
+    """Spacing / origin / direction of the volume at `path` without decoding it (the first 352 bytes): an
+    :class:`Image` over an empty array.  (The maps carry the geometry of the last echo's image,
+    run_t2mapping.py:377 / utils/t2map_utils.py:22-24; a rank that writes them need not have decoded that echo.)"""
+    with open(path, "rb") as f:
+        head = f.read(4096)
+    if head[:2] == b"\x1f\x8b":
+        head = zlib.decompressobj(wbits=31).decompress(head, 352)
+    h = _parse_header(head)
+    return Image(np.zeros((0, 0, 0), np.float32), h.spacing, h.origin, h.direction)
+
+
 def GetArrayFromImage(img: Image) -> np.ndarray:
     return img.arr
 

@@ -147,8 +147,20 @@ def test_subject_round_robin_covers_every_subject_once(monkeypatch):
 
 
 # ---- the CLI's --gpus control flow (fetal_t2mapping_amd/cli.py) with gloo, the GPU fit replaced by a stand-in -------
+def _fake_status(e, m):
+    """Per-voxel stand-in for the status byte: 2 (not converged) where the first sample is below 95, else 1; 0 outside."""
+    return np.where(m != 0, np.where(e[0] < 95.0, 2, 1), 0).astype(np.uint8)
+
+
 def _cli_fake_share(e_share, m_share, te_eff, fit, fit_params, prior, norm, solver, precision, device):
-    return torch.from_numpy(_fake_fit(e_share, m_share))
+    """Stand-in for cli._fit_share: same contract -- (packed [6, per]: t2, k, sigma, res, fun, nit bits; status [per])."""
+    e = e_share.numpy() if torch.is_tensor(e_share) else e_share
+    m = m_share.numpy() if torch.is_tensor(m_share) else m_share
+    four = _fake_fit(e, m)
+    fun = np.where(m != 0, e[1] * 0.25, 0.0).astype(np.float32)
+    nit = np.where(m != 0, (np.abs(e[0]) % 17).astype(np.int32) + 1, 0).astype(np.int32)
+    packed = np.concatenate([four, fun[None], nit.view(np.float32)[None]])
+    return torch.from_numpy(packed), torch.from_numpy(_fake_status(e, m))
 
 
 def _cli_fake_subject(vols, masks, keep, te_eff, fit, fit_params, prior, norm, solver, precision, device):
@@ -156,26 +168,42 @@ def _cli_fake_subject(vols, masks, keep, te_eff, fit, fit_params, prior, norm, s
     mask = np.zeros(np.asarray(masks[0]).shape, bool)
     for m in masks:
         mask |= np.asarray(m) != 0
-    out = _fake_fit(e, mask.reshape(-1).astype(np.uint8))
-    return mask, tuple(o.reshape(mask.shape) for o in out), np.where(mask, 1, 0).astype(np.uint8)
+    mflat = mask.reshape(-1).astype(np.uint8)
+    out = _fake_fit(e, mflat)
+    return mask, tuple(o.reshape(mask.shape) for o in out), _fake_status(e, mflat).reshape(mask.shape)
 
 
-def _cli_worker(rank, world, port, root, n_subjects, out):
+def _cli_worker(rank, world, port, root, n_subjects, out, extra_args):
+    import contextlib
+    import io
     import sys
 
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import fake_sitk
 
     from fetal_t2mapping_amd import cli as R
+    from fetal_t2mapping_amd import convergence
 
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), T2FIT_CLI_BACKEND="gloo")
     sitk = fake_sitk.install()
     R._fit_share = _cli_fake_share
     R._fit_subject = _cli_fake_subject
-    R.main(["--path", root, "--csv", "log.csv", "--in_vivo", "--gaussian", "--lf", "--sim", "d1", "--TEs", "114", "202", "299",
-            "--gpus", str(world)])
-    out[rank] = {os.path.relpath(p, root): np.array(img.arr) for p, img in sitk.written.items()}
+    study = {}
+
+    def fake_study(ada_path, echo_vols, mask_indices, t2_map, nit_map, fun_map, TEeffs, fit, fit_params, prior, norm, sub, ses,
+                   sim, **kw):  # what the figures would be drawn from
+        study.update(rows=None if kw.get("rows") is None else np.array(kw["rows"]), picks=kw.get("picks"),
+                     nit=np.array(nit_map), fun=np.array(fun_map), mask_indices=np.array(mask_indices), have_vols=echo_vols is not None)
+        return []
+
+    convergence.convergence_study = fake_study
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        R.main(["--path", root, "--csv", "log.csv", "--in_vivo", "--gaussian", "--lf", "--sim", "d1", "--TEs", "114", "202", "299",
+                "--gpus", str(world)] + list(extra_args))
+    out[rank] = {"files": {os.path.relpath(p, root): np.array(img.arr) for p, img in sitk.written.items()},
+                 "decoded": dict(R.DECODED), "stdout": buf.getvalue(), "study": study}
 
 
 def _cli_tree(tmp_path, n_subjects, shape):
@@ -191,37 +219,107 @@ def _cli_tree(tmp_path, n_subjects, shape):
     rows, data = [], {}
     for s in range(n_subjects):
         vols = rng.normal(100.0, 10.0, size=(3,) + shape).astype(np.float32)
-        mask = (rng.random(shape) < 0.5).astype(np.uint8)
-        data[f"sub-{s + 1:03d}"] = (vols, mask)
+        masks = [(rng.random(shape) < 0.5).astype(np.uint8) for _ in range(3)]  # per-echo masks differ: the union matters
+        data[f"sub-{s + 1:03d}"] = (vols, masks)
         for i, t in enumerate((114, 202, 299)):
             acq = {"prj": "prj-950", "sub": f"sub-{s + 1:03d}", "ses": "ses-01", "run": f"run-{i + 1:02d}", "EchoTime": t / 1000.0,
                    "CoilString": "HeadNeck"}
             rows.append(acq)
             np.save(R.get_img_path(bids, acq, R.recon_dirname).replace(" ", "") + ".npy", vols[i])
-            np.save(R.get_img_path(bids, acq, R.mask_dirname).replace(" ", "") + ".npy", mask)
+            np.save(R.get_img_path(bids, acq, R.mask_dirname).replace(" ", "") + ".npy", masks[i])
     pd.DataFrame(rows).to_csv(os.path.join(root, "dicom", "logs", "log.csv"), index=False)
     return root, data
+
+
+def _check_files(written, data):
+    for sub, (vols, masks) in data.items():
+        union = (np.sum(np.stack(masks), axis=0) > 0).astype(np.uint8)
+        want = _fake_fit(vols.reshape(3, -1), union.reshape(-1))
+        for j, tag in enumerate(("t2", "k", "sigma", "res")):
+            key = [p for p in written if sub in p and f"_{tag}map_" in p]
+            assert len(key) == 1, (sub, tag, list(written))
+            assert np.array_equal(written[key[0]].reshape(-1), want[j]), (sub, tag)
 
 
 @pytest.mark.parametrize("n_subjects", [1, 3])
 def test_cli_gpus_control_flow_two_ranks(tmp_path, n_subjects):
     """`--gpus 2` as torch.distributed.run would start it (two ranks, gloo instead of RCCL, the fit a per-voxel
-    stand-in).  One subject: the volume is cut over the ranks in hash-dealt chunks, the maps are all-gathered and
-    rank 0 alone writes the four files, equal to the stand-in applied to the whole volume.  Three subjects: they are
-    dealt to the ranks (0 and 2 to rank 0, 1 to rank 1), nothing is exchanged, each rank writes its own files."""
+    stand-in).  One subject: the volume is shared -- each rank decodes its echo files only, the shares are swapped by
+    one all-to-all, the maps are all-gathered and rank 0 alone writes the four files, equal to the stand-in applied to
+    the whole volume.  Three subjects: they are dealt to the ranks (0 and 2 to rank 0, 1 to rank 1), nothing is
+    exchanged, each rank writes its own files."""
     root, data = _cli_tree(tmp_path, n_subjects, (3, 40, 300))  # 36 000 voxels: three chunks, the last one ragged
     mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
-    mp.spawn(_cli_worker, args=(2, _free_port(), root, n_subjects, out), nprocs=2, join=True)
-    written = {**out[0], **out[1]}
+    mp.spawn(_cli_worker, args=(2, _free_port(), root, n_subjects, out, ()), nprocs=2, join=True)
+    written = {**out[0]["files"], **out[1]["files"]}
     if n_subjects == 1:
-        assert len(out[0]) == 4 and len(out[1]) == 0
+        assert len(out[0]["files"]) == 4 and len(out[1]["files"]) == 0
+        # decode work is split: echoes 0 and 2 (and their masks) on rank 0, echo 1 on rank 1
+        assert out[0]["decoded"] == {"echo": 2, "mask": 2} and out[1]["decoded"] == {"echo": 1, "mask": 1}
     else:
-        assert len(out[0]) == 8 and len(out[1]) == 4
-        assert all("sub-002" in p for p in out[1]) and not any("sub-002" in p for p in out[0])
-    for sub, (vols, mask) in data.items():
-        want = _fake_fit(vols.reshape(3, -1), mask.reshape(-1))
-        for j, tag in enumerate(("t2", "k", "sigma", "res")):
-            key = [p for p in written if sub in p and f"_{tag}map_" in p]
-            assert len(key) == 1, (sub, tag, list(written))
-            assert np.array_equal(written[key[0]].reshape(-1), want[j]), (sub, tag)
+        assert len(out[0]["files"]) == 8 and len(out[1]["files"]) == 4
+        assert all("sub-002" in p for p in out[1]["files"]) and not any("sub-002" in p for p in out[0]["files"])
+        assert out[0]["decoded"] == {"echo": 6, "mask": 6} and out[1]["decoded"] == {"echo": 3, "mask": 3}
+    _check_files(written, data)
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_cli_shared_volume_status_and_plots(tmp_path, world):
+    """One subject over 2 / 3 / 4 ranks (4: more ranks than echo files -- rank 3 decodes nothing and still fits its
+    share): maps bit-identical to the whole-volume stand-in, each rank decodes 1/G of the files, the per-voxel status is
+    gathered -- so the `FAIL : Optimization failed for N voxels` line (run_t2mapping.py:298-303) reports the true count,
+    on every rank -- and --plots gets nit / fun maps plus the sampled voxels' rows from the ranks that hold each echo."""
+    root, data = _cli_tree(tmp_path, 1, (3, 40, 300))
+    vols, masks = data["sub-001"]
+    union = (np.sum(np.stack(masks), axis=0) > 0).astype(np.uint8).reshape(-1)
+    e = vols.reshape(3, -1)
+    n_fail = int(np.sum(_fake_status(e, union) == 2))
+    assert n_fail > 100
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_cli_worker, args=(world, _free_port(), root, 1, out, ("--plots", "--plot_seed", "3")), nprocs=world, join=True)
+    _check_files(out[0]["files"], data)
+    for r in range(world):
+        assert len(out[r]["files"]) == (4 if r == 0 else 0)
+        n_mine = len(range(r, 3, world))
+        assert out[r]["decoded"] == {"echo": n_mine, "mask": n_mine}, (r, out[r]["decoded"])
+        assert f"FAIL : Optimization failed for {n_fail} voxels" in out[r]["stdout"]
+    st = out[0]["study"]
+    idx = np.flatnonzero(union)
+    assert not st["have_vols"] and np.array_equal(st["mask_indices"], idx)
+    sel = idx[list(st["picks"][0]) + list(st["picks"][1])]
+    assert len(sel) == 70 and np.array_equal(st["rows"], e[:, sel].T)
+    assert np.array_equal(st["fun"].reshape(-1), np.where(union != 0, e[1] * 0.25, 0.0).astype(np.float32))
+    assert np.array_equal(st["nit"].reshape(-1), np.where(union != 0, (np.abs(e[0]) % 17).astype(np.int32) + 1, 0))
+
+
+def _exchange_worker(rank, world, port, n_vox, n_te, chunk, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(8)
+    echoes = rng.normal(size=(n_te, n_vox)).astype(np.float32)
+    masks = (rng.random((n_te, n_vox)) < 0.3).astype(np.uint8)
+    mine = t2dist.echoes_of_rank(n_te, rank, world)
+    share = t2dist.exchange_echo_shares(torch.from_numpy(echoes[mine].reshape(len(mine), n_vox)), n_te, n_vox, chunk).numpy()
+    want, _ = t2dist.take_cyclic(echoes, None, rank, world, chunk)
+    part = np.zeros(n_vox, np.uint8)
+    for i in mine:
+        part |= masks[i]
+    union = t2dist.union_mask_over_ranks(torch.from_numpy(part))
+    m_share = t2dist.share_of(union, n_vox, rank, world, chunk).numpy()
+    _, want_m = t2dist.take_cyclic(echoes, masks.max(axis=0), rank, world, chunk)
+    out[rank] = bool(np.array_equal(share, want) and np.array_equal(m_share, want_m))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_vox,n_te,chunk", [(2, 1000, 3, 64), (3, 1001, 8, 64), (4, 10, 3, 4), (2, 1, 2, 16), (3, 5000, 6, 256)])
+def test_echo_share_exchange_equals_the_cut_of_the_whole_stack(world, n_vox, n_te, chunk):
+    """Each rank holds only the echoes i = rank, rank + G, ...; after ONE all-to-all it holds every echo of its share of
+    the voxels -- bit for bit what take_cyclic cuts out of the complete stack -- and the all-reduced union mask's share
+    equals the share of the union (ragged sizes, more ranks than echoes, uneven echo counts per rank)."""
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_exchange_worker, args=(world, _free_port(), n_vox, n_te, chunk, out), nprocs=world, join=True)
+    assert all(out[r] for r in range(world)) and len(out) == world
