@@ -13,12 +13,16 @@ all-gather puts the four maps of the whole volume on every rank.  `--scaling wea
 volume (round 1's mode).  `value` = dense voxels of the volume(s) / wall time (max over ranks) in Mvoxel/s.
 
 The JSON line also carries
-  roofline     : achieved algorithmic HBM GB/s of the fit kernel (49 B/voxel at 8 TE: 4*nTE samples + 1 mask byte
-                 + 4 float32 maps) over its mean launch duration on rank 0, measured with HIP events
-                 on the launch stream inside the library, against 8 TB/s.
+  roofline     : achieved algorithmic HBM GB/s of the dominant kernel, the fit (45 B/voxel at 8 TE: 4*nTE samples + 1
+                 mask byte + the three float32 parameter maps it writes) over its mean launch duration on rank 0,
+                 measured with HIP events on the launch stream inside the library, against 8 TB/s; `epilogue` beside it
+                 is the streaming pass that follows every fit and writes the fourth map, `res` (49 B/voxel: samples,
+                 mask, the three maps read back, res written).  SURVEY.md 8d's 49 B/voxel is the two together.
   cpu_baseline : the CPU oracle (oracle/t2fit_oracle.py: the reference's scipy L-BFGS-B loop restated) timed on this
                  host's cores over a bounded sample of the same masked voxels; on the same basis as `value` (dense
                  voxels/s at the bench volume's mask fill), with the fitted-voxel rates of both beside it.
+  cpu_baseline_native : SURVEY.md 8d (ii): the build's own lane solver (the headers the kernels are compiled from, built
+                 by g++ into tests/hostsim: test infrastructure, never loaded by the product) on all host cores.
 """
 import argparse
 import ctypes as C
@@ -141,6 +145,37 @@ def cpu_baseline(echoes_rows, te, fit, prior, seconds):
                       f"L-BFGS-B loop (oracle/t2fit_oracle.py) on a {cores}-process pool, {dt:.1f} s"}
 
 
+def cpu_baseline_native(echoes_rows, te, fit, prior, seconds):
+    """the build's own C++ lane solver on every host core.  tests/hostsim compiles the very headers
+    the HIP kernels are made of with g++ (test infrastructure: the product never loads it); ctypes releases the GIL, so
+    a thread per core runs its own block of rows."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    try:
+        from hostsim import sim
+        sim.lib()
+    except Exception as e:  # not built (no g++ on this box): the figure is optional
+        log(f"native cpu baseline skipped: {e}")
+        return None
+    cores = host_cores()
+    cfg = sim.config(fit, True, te, prior=prior, solver="lbfgsb")
+    t0 = time.perf_counter()
+    sim.fit_rows(cfg, echoes_rows[:2000])
+    per_voxel = (time.perf_counter() - t0) / min(2000, len(echoes_rows))
+    n = int(min(len(echoes_rows), max(cores * 2000, seconds * cores / per_voxel)))
+    blocks = np.array_split(np.arange(n), cores * 4)
+    with ThreadPoolExecutor(cores) as pool:
+        t0 = time.perf_counter()
+        list(pool.map(lambda b: sim.fit_rows(cfg, echoes_rows[b[0]: b[-1] + 1]), [b for b in blocks if len(b)]))
+        dt = time.perf_counter() - t0
+    return {"fitted_value": n / dt / 1e6, "unit": "Mvoxel/s", "cores": cores, "kind": "port",
+            "sample": f"{n} masked voxels of the same slab, the lane solver of fetal_t2mapping_amd/csrc/t2fit_lbfgsb.h compiled "
+                      f"by g++ (tests/hostsim), one thread per core, {dt:.1f} s"}
+
+
 def main():
     a = parse()
     import numpy as np
@@ -159,13 +194,14 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         a.gpus = world
-    cpu = None
+    cpu = cpu_native = None
     if world == 1 and a.cpu_seconds > 0:
         # timed BEFORE this process touches the GPU (the worker pool forks); a thin slab of the
         # same synthetic distribution: same TE vector, k/T2/noise ranges and mask shape
         ev, mv, te_c = synth.brain_volume((6, a.shape[1], a.shape[2]), a.n_te, synth.SEED_BASE + 3)
         rows = np.ascontiguousarray(ev.reshape(a.n_te, -1)[:, mv.reshape(-1) != 0].T)
         cpu = cpu_baseline(rows, te_c, a.fit, not a.no_prior, a.cpu_seconds)
+        cpu_native = cpu_baseline_native(rows, te_c, a.fit, not a.no_prior, min(5.0, a.cpu_seconds))
     log("cpu baseline done" if cpu else "no cpu baseline")
     lib = require_gpu()
     # T2FIT_BENCH_BACKEND=gloo is a REHEARSAL of the N > 1 control flow on a one-GPU box: every rank
@@ -241,7 +277,7 @@ def main():
     # step i runs on stream i % 2 when pipelined (its fit, its all-gather dependency, its reordering), else on the current stream
     streams = [torch.cuda.Stream(), torch.cuda.Stream()] if pipelined else [torch.cuda.current_stream()]
     lib.t2fit_set_timing(1)
-    kernel_ms = []
+    kernel_ms, epilogue_ms, step_wall = [], [], []
     step_no = [0]
 
     def stream_of(b):
@@ -274,6 +310,7 @@ def main():
                     pending[b] = dist.all_gather_into_tensor(gathered[b].view(-1), packed[b].view(-1), async_op=True)
         if record and not pipelined:
             kernel_ms.append(lib.t2fit_last_kernel_ms())  # syncs on the kernel's stop event only
+            step_wall.append(time.perf_counter())
 
     def drain():
         for b in range(2):
@@ -302,6 +339,10 @@ def main():
     elapsed = time.perf_counter() - t0
     if pipelined:  # kernel times of the last timed launches, read now that they are done (no stall inside the region)
         kernel_ms = [lib.t2fit_kernel_ms(k) for k in range(min(a.steps, 16))]
+    epilogue_ms = [lib.t2fit_epilogue_ms(k) for k in range(min(a.steps, 16))]
+    # per-step wall times (one stream: each step ends where the host has seen its fit kernel finish; the 0.2 ms epilogue of
+    # step i runs under the launch of step i + 1, so the last one is inside `elapsed` but in no step of this list)
+    step_ms = [1e3 * (b - a_) for a_, b in zip([t0] + step_wall[:-1], step_wall)] if step_wall else []
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -373,10 +414,21 @@ def main():
         kk = float(np.mean(ks))
         return {"per_gpu_value": round(n_vox / dt2 / 1e6, 3), "per_gpu_fitted_value": round(masked_mine / dt2 / 1e6, 3),
                 "unit": "Mvoxel/s", "ms_per_step": round(dt2 * 1e3, 4), "kernel_ms": round(kk, 4),
-                "roofline_frac": round((4 * a.n_te + 17) * n_vox / (kk * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
+                # bytes the timed kernel moves: the iterative fits write three maps (res comes from their epilogue pass)
+                "roofline_frac": round((4 * a.n_te + (17 if cfg_x.solver == _abi.SOLVER_LOGLIN else 13)) * n_vox / (kk * 1e-3) / 1e9
+                                       / HBM_PEAK_GBS, 6)}
 
-    also = also_f64 = also_loglin = None
+    also = also_f64 = also_loglin = also_rician = also_noprior = None
     if a.solver == "lbfgsb" and a.fit != "rician" and not a.no_also:
+        # the reference's other configurations on the same stack, so that a regression there is visible in this line:
+        # the Rician-likelihood objective (--rician) and the paper's bounds (--no_prior)
+        cfg_r = t2.make_config("rician", t2.fit_table("rician", True), te, prior=not a.no_prior, norm=False, solver="lbfgsb")
+        also_rician = {"solver": "lbfgsb", "fit": "rician", "dtype": "f64", **measure(cfg_r),
+                       "note": "reference-trajectory L-BFGS-B on the Rician negative log-likelihood (run_t2mapping.py:157-177), same stack"}
+        cfg_np = t2.make_config(a.fit, table, te, prior=a.no_prior, norm=False, solver="lbfgsb")
+        also_noprior = {"solver": "lbfgsb", "fit": a.fit, "dtype": "f64", "prior": bool(a.no_prior), **measure(cfg_np),
+                        "note": "the same objective under the other bounds setting (k >= S(TE0), T2 in [10, 2000] when prior is "
+                                "false: run_t2mapping.py:243-245, the paper's in-vivo configuration)"}
         note = ("converged bounded LM of the same objective; differs from the reference's early-stopped result by design "
                 "(DESIGN.md section 2), no all-gather in this figure")
         cfg2 = t2.make_config(a.fit, table, te, prior=not a.no_prior, norm=False, solver="lm", precision="f32")
@@ -398,8 +450,11 @@ def main():
         value = total_vox / (elapsed / a.steps) / 1e6
         fitted_value = total_masked / (elapsed / a.steps) / 1e6
         fill = masked_vol / n_vol
-        bytes_per_voxel = 4 * a.n_te + 1 + 16
+        iterative = a.solver != "loglin" and not (a.solver == "lm" and os.environ.get("T2FIT_ONE_SHOT", "0") != "0")
+        # the iterative fits write t2 / k / sigma; `res` (and its zeros outside the mask) comes from the epilogue pass
+        bytes_per_voxel = 4 * a.n_te + 1 + (12 if iterative else 16)
         k_ms = float(np.mean(kernel_ms))
+        e_ms = float(np.mean([v for v in epilogue_ms if v >= 0] or [0.0]))
         achieved = bytes_per_voxel * n_vox / (k_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
@@ -411,7 +466,9 @@ def main():
         out = {
             "metric": "Mvoxel/s T2 fit, 256\u00b3\u00d78TE 3-param LM, 1/2/4/8 GPU; % HBM roofline",  # BASELINE.json's metric, verbatim
             "value": round(value, 3), "unit": "Mvoxel/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step_median": round(float(np.median(step_ms)), 4) if step_ms else None,
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": "f64" if a.solver == "lbfgsb" else a.precision, "data": "synthetic",
             "basis": f"`value` counts every voxel of the volume (SURVEY.md 8d: dense voxels/s); mask fill {fill:.3f}: "
                      f"`fitted_value` counts the voxels inside the mask, the only ones that are fitted",
@@ -432,14 +489,19 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel": "loglin_volume_kernel" if a.solver == "loglin" else "fit_persistent_kernel",
-                         "kernel_ms": round(k_ms, 4),
+                         "kernel_ms": round(k_ms, 4), "kernel_ms_median": round(float(np.median(kernel_ms)), 4),
+                         "epilogue": ({"kernel": "residuals_kernel", "kernel_ms": round(e_ms, 4), "bytes_per_voxel": 4 * a.n_te + 17,
+                                       "achieved": round((4 * a.n_te + 17) * n_vox / (e_ms * 1e-3) / 1e9, 3) if e_ms > 0 else None,
+                                       "note": "streaming pass after every iterative fit: residual map (4 B/voxel written) from the "
+                                               "samples, the mask and the three parameter maps read back; inside `ms_per_step`"}
+                                      if iterative else None),
                          "kernel_ms_note": ("steps alternate between two streams: a launch's start-to-end time includes the "
                                             "drain of the launch before it, which it overlaps" if pipelined else None),
                          "bytes_per_voxel": bytes_per_voxel, "voxels_per_launch": n_vox,
                          "note": ("one streaming pass, HBM bound" if a.solver == "loglin" else
                                   "the fit is float64 VALU-issue bound (about 4500 wave instructions per evaluation round; "
-                                  "its LDS-resident correction pairs allow six waves per CU), not HBM bound: see DESIGN.md "
-                                  "section 6 and `alu`")},
+                                  "eight one-wave workgroups per CU, two per SIMD), not HBM bound: see DESIGN.md section 6 "
+                                  "and `alu`; bytes_per_voxel counts what THIS kernel moves (samples, mask, three maps)")},
         }
         if reserve_ab is not None:
             reserve_ab["value"] = round(total_vox / (reserve_ab["ms_per_step"] * 1e-3) / 1e6, 3)
@@ -453,6 +515,13 @@ def main():
             cpu["basis"] = (f"`value` = dense-volume equivalent: the fitted-voxel rate divided by the bench volume's mask fill "
                             f"{fill:.3f} (same basis as the headline `value`); `fitted_value` = masked voxels/s as timed")
             out["cpu_baseline"] = cpu
+        if cpu_native is not None:
+            cpu_native["value"] = cpu_native["fitted_value"] / fill
+            out["cpu_baseline_native"] = cpu_native
+        if also_rician is not None:
+            out["also_rician"] = also_rician
+        if also_noprior is not None:
+            out["also_noprior"] = also_noprior
         if also is not None:
             out["also"] = also
         if also_f64 is not None:

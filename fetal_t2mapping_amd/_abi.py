@@ -62,6 +62,7 @@ SYMBOLS = [
     ("t2fit_set_reserve_cus", C.c_int, [C.c_int]),
     ("t2fit_kernel_ms", C.c_double, [C.c_int]),
     ("t2fit_last_kernel_ms", C.c_double, []),
+    ("t2fit_epilogue_ms", C.c_double, [C.c_int]),
     ("t2fit_last_error", C.c_char_p, []),
     ("t2fit_abi_version", C.c_int, []),
 ]

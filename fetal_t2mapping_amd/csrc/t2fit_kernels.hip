@@ -20,6 +20,7 @@
 #endif
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -48,8 +49,12 @@ constexpr int kWaveHint = T2_WAVE_HINT;  // occupancy the register allocator / s
 int g_waves_per_cu = 0;         // T2FIT_WAVES_PER_CU: cap of the above (A/B runs)
 int g_wave_wg = 1;         // one-wave workgroups for the large-volume L-BFGS-B kernels (T2FIT_WAVE_WG=0: 256-lane workgroups)
 int g_persistent_blocks = 2048;  // grid of the persistent kernel (T2FIT_PERSISTENT_BLOCKS overrides)
-bool g_reserve_set = false;      // t2fit_set_reserve_cus() was called: it wins over the environment
-int g_reserve_cus = 0;           // T2FIT_RESERVE_CUS: CUs the one-workgroup-per-CU L-BFGS-B kernel leaves free
+// Process-wide tuning state.  Everything in this block except g_reserve_cus is written once, by the first launch of the
+// process (the T2FIT_* environment switches, read under a function-local static's lock) and only read afterwards.
+// g_reserve_cus can be set at any time from any thread (t2fit_set_reserve_cus) while other threads launch: atomic.
+// None of it can change a result: the maps do not depend on how many workgroups fit a volume.
+std::atomic<bool> g_reserve_set{false};  // t2fit_set_reserve_cus() was called: it wins over the environment
+std::atomic<int> g_reserve_cus{0};       // T2FIT_RESERVE_CUS: CUs' worth of workgroups the L-BFGS-B kernel is launched short
 bool g_nte_special = true;       // T2FIT_NTE_SPECIAL=0: always the generic-echo-count lane (A/B switch)
 int g_park_min = 1;              // T2FIT_PARK_MIN: lanes of a wave that must be waiting for begin() before it runs (A/B switch)
 
@@ -58,7 +63,7 @@ thread_local bool g_timing = false;
 // start / stop events of the last kEvRing timed launches (a caller that pipelines launches over several streams reads a
 // launch's time a few launches later, when it is long done, instead of stalling on the one just queued)
 constexpr int kEvRing = 16;
-thread_local hipEvent_t g_ev0[kEvRing] = {}, g_ev1[kEvRing] = {};
+thread_local hipEvent_t g_ev0[kEvRing] = {}, g_ev1[kEvRing] = {}, g_ev2[kEvRing] = {};  // start, end of the fit kernel, end of the epilogue pass
 thread_local long g_ev_count = 0;   // timed launches so far
 thread_local int g_ev_slot = 0;     // ring slot of the launch being queued
 
@@ -894,7 +899,7 @@ FitKernel pick_kernel(const t2fit_config& c) {
 template <class A, bool kLargeOnly = false, bool kWaveOnly = false>
 hipError_t launch_persistent(unsigned grid, size_t lds_samples, hipStream_t st, const LaneParams& P,
                              const float* echoes, int layout, const uint8_t* mask, int64_t n_vox, const DevMaps& dm,
-                             unsigned long long* counter) {
+                             unsigned long long* counter, bool big) {
   constexpr int W = A::kWavesPerSimd;
   const bool extras = dm.r2 || dm.se || dm.fun || dm.nit || dm.status || dm.xd || dm.fund;
 #if !defined(T2_PHASE_STAMPS)
@@ -958,7 +963,7 @@ hipError_t launch_persistent(unsigned grid, size_t lds_samples, hipStream_t st, 
                      : fit_persistent_kernel<A, kChunkLarge, false, W, false>;
   if constexpr (!kLargeOnly) {
     if (dm.trace) kern = fit_persistent_kernel<A, kChunkSmall, true, W>;
-    else if (n_vox <= kSmallVolume) kern = fit_persistent_kernel<A, kChunkSmall, false, W>;
+    else if (!big) kern = fit_persistent_kernel<A, kChunkSmall, false, W>;
   }
   const size_t lds = ((lds_samples / sizeof(float) + 1) & ~(size_t)1) * sizeof(float) +
                      (size_t)A::kHistDoubles * kBlock * sizeof(double) +
@@ -983,21 +988,21 @@ hipError_t launch_lbfgsb(int n_te, bool large, unsigned grid, size_t lds_samples
                          const float* echoes, int layout, const uint8_t* mask, int64_t n_vox, const DevMaps& dm,
                          unsigned long long* counter) {
   if (large && g_nte_special) {
-    if (n_te == 8) return launch_persistent<LbfgsbLane<MODEL, 8>, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);
-    if (n_te == 6) return launch_persistent<LbfgsbLane<MODEL, 6>, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);
-    if (n_te == 3) return launch_persistent<LbfgsbLane<MODEL, 3>, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);
+    if (n_te == 8) return launch_persistent<LbfgsbLane<MODEL, 8>, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter, large);
+    if (n_te == 6) return launch_persistent<LbfgsbLane<MODEL, 6>, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter, large);
+    if (n_te == 3) return launch_persistent<LbfgsbLane<MODEL, 3>, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter, large);
     // 7 / 5 / 4 echoes: the one-wave-workgroup kernels only (16.2 -> 12.6 ms at 5 echoes against the generic lane)
     {
       hipError_t e = hipErrorNotSupported;
       if (g_wave_wg == 1) {
-        if (n_te == 7) e = launch_persistent<LbfgsbLane<MODEL, 7>, true, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);
-        if (n_te == 5) e = launch_persistent<LbfgsbLane<MODEL, 5>, true, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);
-        if (n_te == 4) e = launch_persistent<LbfgsbLane<MODEL, 4>, true, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);
+        if (n_te == 7) e = launch_persistent<LbfgsbLane<MODEL, 7>, true, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter, large);
+        if (n_te == 5) e = launch_persistent<LbfgsbLane<MODEL, 5>, true, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter, large);
+        if (n_te == 4) e = launch_persistent<LbfgsbLane<MODEL, 4>, true, true>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter, large);
       }
       if (e != hipErrorNotSupported) return e;
     }
   }
-  return launch_persistent<LbfgsbLane<MODEL>>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter);
+  return launch_persistent<LbfgsbLane<MODEL>>(grid, lds_samples, st, P, echoes, layout, mask, n_vox, dm, counter, large);
 }
 
 int check_common(const t2fit_config* cfg, const void* echoes, int layout, int64_t n_vox) {
@@ -1018,14 +1023,15 @@ bool loglin_vec_ok(const float* echoes, int layout, const uint8_t* mask, int64_t
          al(dm.k, 16) && al(dm.sigma, 16) && al(dm.res, 16) && (size_t)n_te * kLoglinTile * sizeof(float) <= 65536;
 }
 
+// part_of_large: this call fits one slab of a large volume (the host seam): the large-volume kernels whatever its size
 int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const uint8_t* mask, int64_t n_vox,
-               const DevMaps& dm, hipStream_t st) {
+               const DevMaps& dm, hipStream_t st, bool part_of_large = false) {
   if (n_vox == 0) return T2FIT_OK;
   static const bool env_read = [] {  // tuning / A-B switches, read once
     if (const char* e = std::getenv("T2FIT_ONE_SHOT")) g_use_persistent = std::atoi(e) == 0;
     if (const char* e = std::getenv("T2FIT_PERSISTENT_BLOCKS")) g_persistent_blocks = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("T2FIT_REFILL_MIN")) g_refill_min = std::min(64, std::max(1, std::atoi(e)));
-    if (const char* e = std::getenv("T2FIT_RESERVE_CUS"); e && !g_reserve_set) g_reserve_cus = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("T2FIT_RESERVE_CUS"); e && !g_reserve_set.load()) g_reserve_cus.store(std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("T2FIT_NTE_SPECIAL")) g_nte_special = std::atoi(e) != 0;
     if (const char* e = std::getenv("T2FIT_TAKE")) g_take = std::max(0, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("T2FIT_SMALL_VOLUME")) kSmallVolume = std::max<int64_t>(0, std::atoll(e));
@@ -1052,26 +1058,31 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
     if (!g_ev0[g_ev_slot]) {
       T2_HIP(hipEventCreate(&g_ev0[g_ev_slot]));
       T2_HIP(hipEventCreate(&g_ev1[g_ev_slot]));
+      T2_HIP(hipEventCreate(&g_ev2[g_ev_slot]));
     }
     T2_HIP(hipEventRecord(g_ev0[g_ev_slot], st));
   }
   if (persistent) {
     // one workgroup per CU slot; not required to be co-resident (work comes from an atomic queue)
-    const int kChunk = (dm.trace || n_vox <= kSmallVolume) ? kChunkSmall : kChunkLarge;
+    const bool big = !dm.trace && (part_of_large || n_vox > kSmallVolume);
+    const int kChunk = big ? kChunkLarge : kChunkSmall;
     const int64_t chunks = (n_vox + kChunk - 1) / kChunk;
     unsigned pgrid = (unsigned)std::min<int64_t>((chunks + 3) / 4, g_persistent_blocks);
-    if (g_reserve_cus > 0 && cfg->solver == T2FIT_SOLVER_LBFGSB) {
-      // this kernel's workgroup fills a CU (LDS): a grid of (CUs - reserve) leaves whole CUs to kernels of other
-      // streams (RCCL's all-gather beside the next fit), which otherwise could not start before it drains
+    const int reserve = g_reserve_cus.load(std::memory_order_relaxed);
+    if (reserve > 0 && cfg->solver == T2FIT_SOLVER_LBFGSB) {
+      // The resident workgroups of this kernel hold all of a CU's LDS.  Launched `reserve` CUs' worth of workgroups
+      // short, the chip keeps that many workgroup slots (LDS and wave slots) free for kernels of other streams (RCCL's
+      // all-gather beside the next fit), which otherwise could not become resident before this one drains.  With
+      // one-wave workgroups the dispatcher spreads the shortfall over the CUs it likes: free slots, not whole CUs.
       int dev = 0, cus = 0;
       T2_HIP(hipGetDevice(&dev));
       T2_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-      pgrid = std::min<unsigned>(pgrid, (unsigned)std::max(1, cus - g_reserve_cus));
+      pgrid = std::min<unsigned>(pgrid, (unsigned)std::max(1, cus - reserve));
     }
     hipError_t pe;
-#define T2_PERSIST(...) pe = launch_persistent<__VA_ARGS__>(pgrid, lds, st, P, echoes, layout, mask, n_vox, dm, counter)
+#define T2_PERSIST(...) pe = launch_persistent<__VA_ARGS__>(pgrid, lds, st, P, echoes, layout, mask, n_vox, dm, counter, big)
     if (cfg->solver == T2FIT_SOLVER_LBFGSB) {
-      const bool large = !dm.trace && n_vox > kSmallVolume;
+      const bool large = big;
 #define T2_LBFGSB(M) pe = launch_lbfgsb<M>(cfg->n_te, large, pgrid, lds, st, P, echoes, layout, mask, n_vox, dm, counter)
       if (cfg->model == T2FIT_MODEL_GAUSSIAN) T2_LBFGSB(T2FIT_MODEL_GAUSSIAN);
       else if (cfg->model == T2FIT_MODEL_GAUSSIAN_RICIAN) T2_LBFGSB(T2FIT_MODEL_GAUSSIAN_RICIAN);
@@ -1079,13 +1090,13 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
 #undef T2_LBFGSB
     } else {
       // converged LM lane; on large volumes with a common echo-train length the echo-count specialisation
-      const bool large = !dm.trace && n_vox > kSmallVolume && g_nte_special;
+      const bool large = big && g_nte_special;
       const bool f32 = cfg->precision == T2FIT_PREC_F32, two = cfg->model == T2FIT_MODEL_GAUSSIAN;
 #define T2_LM(T, NPAR)                                                                                                 \
   do {                                                                                                                 \
-    if (large && cfg->n_te == 8) pe = launch_persistent<LmLaneAdaptor<T, NPAR, 8>, true>(pgrid, lds, st, P, echoes, layout, mask, n_vox, dm, counter); \
-    else if (large && cfg->n_te == 6) pe = launch_persistent<LmLaneAdaptor<T, NPAR, 6>, true>(pgrid, lds, st, P, echoes, layout, mask, n_vox, dm, counter); \
-    else if (large && cfg->n_te == 3) pe = launch_persistent<LmLaneAdaptor<T, NPAR, 3>, true>(pgrid, lds, st, P, echoes, layout, mask, n_vox, dm, counter); \
+    if (large && cfg->n_te == 8) pe = launch_persistent<LmLaneAdaptor<T, NPAR, 8>, true>(pgrid, lds, st, P, echoes, layout, mask, n_vox, dm, counter, large); \
+    else if (large && cfg->n_te == 6) pe = launch_persistent<LmLaneAdaptor<T, NPAR, 6>, true>(pgrid, lds, st, P, echoes, layout, mask, n_vox, dm, counter, large); \
+    else if (large && cfg->n_te == 3) pe = launch_persistent<LmLaneAdaptor<T, NPAR, 3>, true>(pgrid, lds, st, P, echoes, layout, mask, n_vox, dm, counter, large); \
     else T2_PERSIST(LmLaneAdaptor<T, NPAR>);                                                                           \
   } while (0)
       // (float32 stays on the generic lane: the specialised evaluation keeps eight echoes in flight, which does not fit
@@ -1099,12 +1110,13 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
     }
 #undef T2_PERSIST
     if (pe != hipSuccess) return fail(T2FIT_E_HIP, std::string("persistent fit launch: ") + hipGetErrorString(pe));
-    if (g_timing) {  // the timed kernel is the fit; the epilogue pass is a separate, HBM-bound launch
-      T2_HIP(hipEventRecord(g_ev1[g_ev_slot], st));
-      ++g_ev_count;
-    }
+    if (g_timing) T2_HIP(hipEventRecord(g_ev1[g_ev_slot], st));  // the fit kernel ends here; the epilogue pass is a separate, HBM-bound launch
     hipLaunchKernelGGL(residuals_kernel, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox,
                        (const float*)dm.t2, (const float*)dm.k, (const float*)dm.sigma, dm.res, dm.r2, dm.se);
+    if (g_timing) {
+      T2_HIP(hipEventRecord(g_ev2[g_ev_slot], st));
+      ++g_ev_count;
+    }
   } else if (loglin && loglin_vec_ok(echoes, layout, mask, n_vox, dm, cfg->n_te)) {
     const bool extras = dm.r2 || dm.se || dm.fun || dm.nit || dm.status || dm.xd || dm.fund;
     hipLaunchKernelGGL(extras ? loglin_volume_kernel<true> : loglin_volume_kernel<false>,
@@ -1114,8 +1126,9 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox, dm);
   }
   T2_HIP(hipGetLastError());
-  if (g_timing && !persistent) {
+  if (g_timing && !persistent) {  // one-pass kernels: no epilogue (its time reads 0)
     T2_HIP(hipEventRecord(g_ev1[g_ev_slot], st));
+    T2_HIP(hipEventRecord(g_ev2[g_ev_slot], st));
     ++g_ev_count;
   }
 #if defined(T2_PHASE_STAMPS)
@@ -1185,10 +1198,8 @@ int t2fit_device_count(void) {
 }
 
 int t2fit_set_reserve_cus(int cus) {
-  const int before = g_reserve_cus;
-  g_reserve_cus = std::max(0, cus);
-  g_reserve_set = true;
-  return before;
+  g_reserve_set.store(true);
+  return g_reserve_cus.exchange(std::max(0, cus));
 }
 
 int t2fit_set_timing(int enabled) {
@@ -1207,6 +1218,15 @@ double t2fit_kernel_ms(int launches_ago) {
 }
 
 double t2fit_last_kernel_ms(void) { return t2fit_kernel_ms(0); }
+
+double t2fit_epilogue_ms(int launches_ago) {
+  if (launches_ago < 0 || launches_ago >= kEvRing || launches_ago >= g_ev_count) return -1.0;
+  const int slot = (int)((g_ev_count - 1 - launches_ago) % kEvRing);
+  if (hipEventSynchronize(g_ev2[slot]) != hipSuccess) return -1.0;
+  float ms = 0.0f;
+  if (hipEventElapsedTime(&ms, g_ev1[slot], g_ev2[slot]) != hipSuccess) return -1.0;
+  return (double)ms;
+}
 
 int t2fit_volume_dev(const t2fit_config* cfg, const float* echoes_dev, int layout, const uint8_t* mask_dev,
                      int64_t n_vox, const t2fit_maps* maps, void* stream) {
@@ -1291,7 +1311,7 @@ int t2fit_context_volume_host(t2fit_context* c, const t2fit_config* cfg, const f
   T2_HIP(hipSetDevice(c->device));
   const int n_te = cfg->n_te;
   // Slabs of about 2.4 M voxels (multiples of 4096, so that every slab keeps the alignment the vectorised kernels
-  // want and stays on the large-volume kernels): short enough that filling and draining the pipeline costs little,
+  // want; every slab of a large volume runs the large-volume kernels, also the short first and last ones): short enough that filling and draining the pipeline costs little,
   // long enough that a slab's fit covers the host-side copies of its neighbours.  The first slab is a quarter of
   // that: the device starts working after a quarter of the copy time.
   int64_t slab = (int64_t)9 << 18;  // 2,359,296
@@ -1460,7 +1480,7 @@ int t2fit_context_volume_host(t2fit_context* c, const t2fit_config* cfg, const f
                maps->fun ? fm[5] + lo : nullptr, maps->t2_se ? fm[6] + lo : nullptr,
                maps->nit ? (int32_t*)(buf + off_nit) + lo : nullptr,
                maps->status ? (uint8_t*)(buf + off_status) + lo : nullptr, nullptr, nullptr};
-    rc = launch_fit(cfg, d_e, layout, dmask, len, dm, c->s_fit);
+    rc = launch_fit(cfg, d_e, layout, dmask, len, dm, c->s_fit, n_vox > kSmallVolume);
     if (rc != T2FIT_OK) { cleanup(); return rc; }
     T2_HIP_C(hipEventRecord(ev_fit[k], c->s_fit));
     // the device -> host copy of the previous slab is queued behind this slab's host -> device copy: both directions

@@ -252,6 +252,12 @@ def fit_volume(echoes, mask, TEeffs, fit, fit_params, prior=True, norm=False, *,
                 out.status = torch.empty(spatial, dtype=torch.uint8, device=dev)
         for name in ("t2", "k", "sigma", "res", "r2", "fun", "nit", "status", "t2_se"):
             t = getattr(out, name)
+            if t is not None:  # the library writes raw bytes of this type through the pointer: check before it does
+                want = {"nit": torch.int32, "status": torch.uint8}.get(name, torch.float32)
+                if not (torch.is_tensor(t) and t.dtype == want and t.device == dev and t.is_contiguous() and t.numel() == n):
+                    raise ValueError(f"out.{name} must be a contiguous {str(want).split('.')[-1]} tensor on {dev} with {n} elements")
+            elif name in ("t2", "k", "sigma", "res"):
+                raise ValueError(f"out.{name} is required")
             setattr(maps, name, None if t is None else t.data_ptr())
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream().cuda_stream
@@ -277,8 +283,12 @@ def fit_volume(echoes, mask, TEeffs, fit, fit_params, prior=True, norm=False, *,
         out.status = _new_map(spatial, np.uint8)
     for name in ("t2", "k", "sigma", "res", "r2", "fun", "nit", "status", "t2_se"):
         a = getattr(out, name)
-        if a is not None and not (isinstance(a, np.ndarray) and a.flags.c_contiguous and a.size == n):
-            raise ValueError(f"out.{name} must be a C-contiguous numpy array of the spatial shape")
+        want = {"nit": np.int32, "status": np.uint8}.get(name, np.float32)  # what the library writes through the pointer
+        if a is not None and not (isinstance(a, np.ndarray) and a.dtype == want and a.flags.c_contiguous
+                                  and a.flags.writeable and a.size == n):
+            raise ValueError(f"out.{name} must be a writable C-contiguous {np.dtype(want).name} numpy array with {n} elements")
+        if a is None and name in ("t2", "k", "sigma", "res"):
+            raise ValueError(f"out.{name} is required")
         setattr(maps, name, None if a is None else a.ctypes.data)
     check(lib.t2fit_volume_host(C.byref(cfg), e.ctypes.data, lay, None if m is None else m.ctypes.data, n,
                                 C.byref(maps), int(device)))

@@ -208,15 +208,21 @@ int t2fit_label_stats_dev(const float *map_dev, const int32_t *label_dev, int64_
  * t2fit_volume_dev call of this thread records HIP events around its fit kernel on the launch stream.
  * t2fit_kernel_ms(k): duration in milliseconds of the fit kernel launched k timed calls ago (0 = the most recent;
  * the last 16 are kept), waiting for that launch to finish if it has not; negative when unavailable.
- * t2fit_last_kernel_ms() = t2fit_kernel_ms(0). */
+ * t2fit_last_kernel_ms() = t2fit_kernel_ms(0).
+ * t2fit_epilogue_ms(k): duration of the streaming epilogue pass (residual map, R^2, T2 standard error) that followed
+ * that fit kernel; 0 for the one-pass kernels (closed form, one-shot LM), which have none. */
 int t2fit_set_timing(int enabled);
 double t2fit_kernel_ms(int launches_ago);
 double t2fit_last_kernel_ms(void);
+double t2fit_epilogue_ms(int launches_ago);
 
-/* Multi-GPU tuning: the reference-trajectory fit is a persistent kernel whose workgroups fill every CU's LDS, so a
- * collective's kernel on another stream (RCCL's all-gather of the previous maps) may not find room before it drains.
- * `cus` > 0 makes the fit leave that many CUs unoccupied (costs cus/256 of its speed); 0 = use them all (default; the
- * environment variable T2FIT_RESERVE_CUS sets the initial value).  Returns the previous setting.  No reference
+/* Multi-GPU tuning: the reference-trajectory fit is a persistent kernel whose resident workgroups hold all of every
+ * CU's LDS, so a collective's kernel on another stream (RCCL's all-gather of the previous maps) may not become resident
+ * before it drains.  `cus` > 0 launches the fit that many CUs' worth of workgroups short (costs cus/256 of its speed):
+ * the chip then keeps that many workgroup slots -- their LDS and wave slots -- free; with the one-wave workgroups of the
+ * large-volume kernels the dispatcher spreads them over the CUs of its choice (free slots, not whole CUs).  0 = use
+ * everything (default; the environment variable T2FIT_RESERVE_CUS sets the initial value).  Process-wide, may be called
+ * from any thread at any time (atomic); never changes a result.  Returns the previous setting.  No reference
  * counterpart (the reference is single-process). */
 int t2fit_set_reserve_cus(int cus);
 

@@ -1175,6 +1175,55 @@ def test_sharded_path_with_rccl_single_rank(t2):
         dist.destroy_process_group()
 
 
+def test_cli_shared_volume_path_on_device(t2, tmp_path):
+    """cli._fit_subject_shared end to end on the device (RCCL backend, world size 1 is all one GPU box allows): NIfTI
+    files -> pinned block -> device, union mask by all-reduce, the all-to-all of echo shares, the fit with status / nit /
+    fun rows, both all-gathers == plain fit_volume on the same files, bit for bit, status included; with numpy_legacy too.
+    (Ranks > 1: tests/test_dist_gloo.py with gloo, the fit a stand-in.)"""
+    import torch
+    import torch.distributed as dist
+
+    from fetal_t2mapping_amd import cli as R, nifti, synth
+
+    echoes, mask, te = synth.brain_volume((5, 24, 150), 6, seed=11)   # 18 000 voxels: two chunks, the second ragged
+    echoes[2, 2, 10, 40] = np.nan                                     # one voxel the fit refuses: status 3
+    mask[2, 10, 40] = 1
+    rp, mp_ = [], []
+    for i in range(len(te)):
+        rp.append(str(tmp_path / f"e{i}.nii.gz"))
+        mp_.append(str(tmp_path / f"m{i}.nii.gz"))
+        img = nifti.GetImageFromArray(echoes[i])
+        img.SetSpacing((1.0, 1.0, 1.5))
+        nifti.WriteImage(img, rp[-1])
+        m_i = mask.copy()
+        m_i[i % 5, :, :3] = 0  # per-echo masks differ: the union is what is fitted
+        nifti.WriteImage(nifti.GetImageFromArray(m_i), mp_[-1])
+    union = np.zeros(mask.shape, bool)
+    for i in range(len(te)):
+        m_i = mask.copy()
+        m_i[i % 5, :, :3] = 0
+        union |= m_i != 0
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        table = t2.fit_table("rician", True)
+        for legacy in (False, True):
+            before = dict(R.DECODED)
+            got_mask, maps4, status, extras, recon_img, label, my_vols = R._fit_subject_shared(
+                nifti, rp, mp_, None, False, te, "rician", table, True, False, "lbfgsb", "f64", 0, legacy)
+            assert R.DECODED["echo"] - before["echo"] == len(te) and sorted(my_vols) == list(range(len(te)))
+            want = t2.fit_volume(echoes, union.astype(np.uint8), te, "rician", table, extras=True, numpy_legacy=legacy)
+            assert np.array_equal(got_mask, union) and recon_img.GetSpacing() == (1.0, 1.0, 1.5)
+            for j, name in enumerate(("t2", "k", "sigma", "res")):
+                assert np.array_equal(maps4[j], getattr(want, name), equal_nan=True), (name, legacy)
+            assert np.array_equal(status, want.status) and status[2, 10, 40] == 3
+            assert np.array_equal(extras["nit"], want.nit) and np.array_equal(extras["fun"], want.fun, equal_nan=True)
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("partition", ["cyclic", "slab"])
 def test_bench_strong_scaling_control_flow_two_ranks_one_gpu(t2, partition):
     """bench.py's N > 1 path rehearsed on the one GPU of this box (two ranks on cuda:0, gather staged through gloo;
@@ -1307,3 +1356,37 @@ def test_host_entry_slab_pipeline_equals_single_piece(t2, monkeypatch):
                 ref, names = one, ("t2", "k", "sigma", "res", "r2", "fun", "nit", "status", "t2_se")
             for name in names:
                 assert np.array_equal(getattr(got, name), getattr(ref, name), equal_nan=True), (slabs, name)
+
+
+def test_out_maps_of_the_wrong_type_are_refused(t2):
+    """fit_volume(out=...) hands raw pointers to the library, which writes 4 bytes per voxel into the float maps and
+    nit, one into status: arrays of another dtype, size, layout or device must be refused before the call (a float16
+    t2 map of the right shape would otherwise be overrun, a float64 one silently half filled)."""
+    import torch
+
+    from fetal_t2mapping_amd import synth
+
+    echoes, mask, te = synth.brain_volume((3, 8, 20), 6, seed=5)
+    table = t2.fit_table("gaussian", True)
+    good = t2.fit_volume(echoes, mask, te, "gaussian", table, extras=True)
+    again = t2.fit_volume(echoes, mask, te, "gaussian", table, out=good)  # the documented reuse still works
+    assert again is good
+    for name, bad in (("t2", np.zeros(mask.shape, np.float16)), ("k", np.zeros(mask.shape, np.float64)),
+                      ("nit", np.zeros(mask.shape, np.int64)), ("status", np.zeros(mask.shape, np.float32)),
+                      ("res", np.zeros(mask.size + 1, np.float32)), ("sigma", np.zeros((mask.size, 2), np.float32)[:, 0])):
+        out = t2.T2Maps(**{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in vars(good).items()})
+        setattr(out, name, bad)
+        with pytest.raises(ValueError, match=f"out.{name}"):
+            t2.fit_volume(echoes, mask, te, "gaussian", table, out=out)
+    dev = torch.device("cuda", 0)
+    e_d, m_d = torch.from_numpy(echoes).to(dev), torch.from_numpy(mask).to(dev)
+    ok = t2.fit_volume(e_d, m_d, te, "gaussian", table, extras=True)
+    torch.cuda.synchronize()
+    for name, bad in (("t2", torch.zeros(mask.shape, dtype=torch.float16, device=dev)),
+                      ("nit", torch.zeros(mask.shape, dtype=torch.int64, device=dev)),
+                      ("k", torch.zeros(mask.shape, dtype=torch.float32)),  # host tensor
+                      ("res", torch.zeros((mask.size, 2), dtype=torch.float32, device=dev)[:, 0])):
+        out = t2.T2Maps(**vars(ok))
+        setattr(out, name, bad)
+        with pytest.raises(ValueError, match=f"out.{name}"):
+            t2.fit_volume(e_d, m_d, te, "gaussian", table, out=out)
