@@ -196,18 +196,28 @@ def save_nifti_maps(t2_map, k_map, sigma_map, res_map, dirname, recon_img, bids_
     print(f"T2 map saved as nifti file in {dirname}")
 
 
-def save_phantom_csv(t2_map, k_map, sigma_map, label, id, gt, bids_path, acq, dirname, sim, analysis, device=0):
-    """utils/t2map_utils.py:30-59: nanmean / nanstd of each map per vial label, reduced on the GPU
-    (t2fit_label_stats_dev: mean, then mean squared deviation from it, as numpy computes them)."""
+def phantom_frame(stats, id, gt):
+    """The table ``save_phantom_csv`` writes (utils/t2map_utils.py:55-66): ``stats`` maps the six column names to
+    per-vial values.  ``np.nanmean`` / ``np.nanstd`` of a float32 map are float32 numbers (stored into float64 arrays,
+    :37-48), so the values are rounded to float32 here; the text pandas then writes has the reference's digits."""
     import pandas as pd
 
+    cols = {name: np.asarray(stats[name], np.float64).astype(np.float32).astype(np.float64)
+            for name in ("meanT2", "stdT2", "meanK", "stdK", "meanC", "stdC")}
+    return pd.DataFrame({"id": id, "trueT2": gt, **cols})
+
+
+def save_phantom_csv(t2_map, k_map, sigma_map, label, id, gt, bids_path, acq, dirname, sim, analysis, device=0):
+    """utils/t2map_utils.py:30-59: nanmean / nanstd of each map per vial label, reduced on the GPU
+    (t2fit_label_stats_dev: mean, then mean squared deviation from it, as numpy computes them -- accumulated in float64
+    where numpy sums the float32 values in float32, then rounded to the float32 numpy returns: the last float32 digit can
+    differ from the reference's file, nothing more)."""
     n_roi = len(gt)
-    cols = {}
+    stats = {}
     for arr, m, s in ((t2_map, "meanT2", "stdT2"), (k_map, "meanK", "stdK"), (sigma_map, "meanC", "stdC")):
-        cols[m], cols[s], _ = t2map.label_stats(arr, label, n_roi, device=device)
-    df = pd.DataFrame({"id": id, "trueT2": gt, **cols})
+        stats[m], stats[s], _ = t2map.label_stats(arr, label, n_roi, device=device)
     path = get_img_path(bids_path, acq.iloc[0], dirname).replace("t2map.nii.gz", f"sim-{sim}_ROI_data_ada-{analysis}.csv")
-    df.to_csv(path, index=False)
+    phantom_frame(stats, id, gt).to_csv(path, index=False)
 
 
 # ---- driver ------------------------------------------------------------------------------------

@@ -11,6 +11,9 @@ the driver makes lets the reference's whole ``process_t2maps`` run (Pool, plots,
 Outputs (committed, data only -- inputs and the reference's outputs):
   voxels_<field>_<mode>_<prior>_te<n>.npz   per-voxel fits: x, success, nit, fun, traces, residuals
   volume_lf_gaussian_noprior.npz             whole process_t2maps run on a 6x12x14x3 volume
+  phantom_lf_gaussian_rician_fast.npz        whole process_t2maps run with phantom=True, fast=True (--in_vitro_fast) on an
+                                             8x40x40x3 phantom: maps, file names and the ROI CSV text (--phantom-only
+                                             regenerates just this one)
 The reference never travels to the GPU box; these files and oracle/ do.
 """
 import os
@@ -199,7 +202,52 @@ def volume_fixture():
     return sorted(names)
 
 
+def phantom_fixture():
+    """The reference's whole ``process_t2maps`` with phantom=True, fast=True (--in_vitro_fast) on a small NIST-phantom-like
+    volume: what it writes, including the ROI CSV of ``save_phantom_csv`` (utils/t2map_utils.py:30-59) as text."""
+    import pandas as pd
+
+    echoes, mask, label, te, gt = synth.phantom_volume((8, 40, 40), 3, synth.SEED_BASE + 2, low_field=True)
+    tmp = tempfile.mkdtemp(prefix="t2golden_ph_")
+    bids = os.path.join(tmp, "projects") + "/"
+    prj, sub, ses = "prj-901", "sub-001", "ses-01"
+    os.makedirs(os.path.join(bids, prj, "ada"))
+    rows = []
+    for i, t in enumerate(te):
+        acq = {"prj": prj, "sub": sub, "ses": ses, "run": f"run-{i + 1:02d}", "EchoTime": t / 1000.0, "CoilString": "HeadNeck"}
+        rows.append(acq)
+        for dirname, arr in ((R.recon_dirname, echoes[i]), (R.mask_dirname, mask), (R.phantom_labels_dirname, label)):
+            np.save(R.get_img_path(bids, acq, dirname).replace(" ", "") + ".npy", arr)
+    fit, fit_params = R.set_fit_params(_args("gaussian_rician", True))
+    import random
+    random.seed(0)
+    sys.modules["SimpleITK"].written.clear()
+    old = sys.stdout
+    sys.stdout = open(os.devnull, "w")
+    try:
+        R.process_t2maps(pd.DataFrame(rows), bids, [int(t) for t in te], fit, fit_params, True, True, True, True, False, "p1")
+    finally:
+        sys.stdout = old
+    written = sys.modules["SimpleITK"].written
+    out, names = {}, []
+    for path, img in written.items():
+        rel = os.path.relpath(path, bids)
+        names.append(rel)
+        out[rel.split("_sim-p1_")[1].split("map_")[0]] = np.asarray(img.arr)
+    csvs = [os.path.join(d, f) for d, _, fs in os.walk(bids) for f in fs if f.endswith(".csv")]
+    assert len(csvs) == 1, csvs
+    np.savez_compressed(
+        os.path.join(HERE, "phantom_lf_gaussian_rician_fast.npz"), echoes=echoes, mask=mask, label=label, te=te,
+        t2=out["t2"], k=out["k"], sigma=out["sigma"], res=out["res"], written=np.array(sorted(names)),
+        csv_name=np.array(os.path.relpath(csvs[0], bids)), csv_text=np.array(open(csvs[0]).read()),
+        numpy_version=np.array(np.__version__), scipy_version=np.array(scipy.__version__))
+    return os.path.relpath(csvs[0], bids), open(csvs[0]).read()
+
+
 def main():
+    if "--phantom-only" in sys.argv:
+        print(*phantom_fixture(), sep="\n")
+        return
     cfg = 0
     for low_field in (True, False):
         for mode in O.MODES:
@@ -210,6 +258,7 @@ def main():
                     cfg += 1
     for n in volume_fixture():
         print("volume wrote", n)
+    print(*phantom_fixture(), sep="\n")
 
 
 if __name__ == "__main__":

@@ -125,3 +125,36 @@ def test_convergence_figures_from_traces(tmp_path, monkeypatch):
     # the gathered rows are rows of the (N, nTE) stack at sampled mask indices
     stack = np.stack([v.reshape(-1) for v in vols], axis=1).astype(np.float32)
     assert all(any(np.array_equal(r, stack[i]) for i in idx) for r in seen["rows"][:5])
+
+
+def test_phantom_csv_text_equals_the_references_file():
+    """tests/golden/phantom_lf_gaussian_rician_fast.npz holds a whole `process_t2maps(phantom=True, fast=True)` run of
+    the reference (make_golden.py::phantom_fixture): its maps and the text of the ROI CSV `save_phantom_csv` wrote
+    (utils/t2map_utils.py:30-59).  From the reference's own maps -- per-vial statistics as numpy computes them on float32
+    maps -- cli.phantom_frame must write that text character for character: column names and order, the swapped
+    `id` / `trueT2` columns (run_t2mapping.py:27 vs :478), float32-valued numbers in pandas' digits."""
+    import io
+    import os
+
+    from conftest import GOLDEN
+    from fetal_t2mapping_amd import cli as R
+
+    d = np.load(os.path.join(GOLDEN, "phantom_lf_gaussian_rician_fast.npz"))
+    label = d["label"]
+    id_, gt_ = R.set_phantom_gt(True)  # the reference's swapped unpacking: `id` holds the T2 values, `gt` the vial names
+    stats = {}
+    for arr, m, s in ((d["t2"], "meanT2", "stdT2"), (d["k"], "meanK", "stdK"), (d["sigma"], "meanC", "stdC")):
+        stats[m] = [np.nanmean(arr[label == i + 1]) for i in range(len(gt_))]
+        stats[s] = [np.nanstd(arr[label == i + 1]) for i in range(len(gt_))]
+    buf = io.StringIO()
+    R.phantom_frame(stats, id_, gt_).to_csv(buf, index=False)
+    assert buf.getvalue() == str(d["csv_text"])
+    assert str(d["csv_name"]).endswith("sub-001_ses-01_recon_1mm_sim-p1_ROI_data_ada-gaussian_rician.csv")
+    # float64-accumulated statistics (what the GPU reduction delivers) land on the same text or one float32 step beside it
+    stats64 = {k: [float(np.float64(v)) for v in vals] for k, vals in stats.items()}
+    for arr, m, s in ((d["t2"], "meanT2", "stdT2"),):
+        stats64[m] = [np.nanmean(arr[label == i + 1].astype(np.float64)) for i in range(len(gt_))]
+        stats64[s] = [np.nanstd(arr[label == i + 1].astype(np.float64)) for i in range(len(gt_))]
+    got = R.phantom_frame(stats64, id_, gt_)
+    want = R.phantom_frame(stats, id_, gt_)
+    assert np.allclose(got["meanT2"], want["meanT2"], rtol=3e-7, atol=0) and np.allclose(got["stdT2"], want["stdT2"], rtol=2e-6, atol=0)

@@ -1390,3 +1390,59 @@ def test_out_maps_of_the_wrong_type_are_refused(t2):
         setattr(out, name, bad)
         with pytest.raises(ValueError, match=f"out.{name}"):
             t2.fit_volume(e_d, m_d, te, "gaussian", table, out=out)
+
+
+def test_phantom_csv_against_the_references_file(t2, tmp_path):
+    """n3 pinned to the reference (tests/golden/phantom_lf_gaussian_rician_fast.npz: the reference's own
+    `process_t2maps(phantom=True, fast=True)` run with the CSV text it wrote).
+    (1) `save_phantom_csv` on the REFERENCE's maps: the GPU reduction rounded to float32 gives the reference's file --
+        same header, same swapped id / trueT2 columns, every number within one float32 step (the reference sums float32
+        values in float32, the kernel in float64).
+    (2) the whole --in_vitro_fast pipeline on the fixture's inputs: only labelled voxels are fitted (zeros elsewhere,
+        bit-exact), same file names, vial means within the fit's own tolerance of the reference's."""
+    import io
+
+    import pandas as pd
+
+    import fake_sitk
+    from fetal_t2mapping_amd import cli as R
+
+    d = np.load(os.path.join(GOLDEN, "phantom_lf_gaussian_rician_fast.npz"))
+    want = pd.read_csv(io.StringIO(str(d["csv_text"])))
+    bids = str(tmp_path / "projects") + "/"
+    te = d["te"]
+    rows = []
+    sitk = fake_sitk.install()
+    os.makedirs(os.path.join(bids, "prj-901", "ada"))
+    for i, t in enumerate(te):
+        acq = {"prj": "prj-901", "sub": "sub-001", "ses": "ses-01", "run": f"run-{i + 1:02d}", "EchoTime": t / 1000.0,
+               "CoilString": "HeadNeck"}
+        rows.append(acq)
+        for dirname, arr in ((R.recon_dirname, d["echoes"][i]), (R.mask_dirname, d["mask"]), (R.phantom_labels_dirname, d["label"])):
+            np.save(R.get_img_path(bids, acq, dirname).replace(" ", "") + ".npy", arr)
+    md = pd.DataFrame(rows)
+    # (1) the reduction + CSV writer alone, on the reference's maps
+    id_, gt_ = R.set_phantom_gt(True)
+    R.save_phantom_csv(d["t2"], d["k"], d["sigma"], d["label"], id_, gt_, bids, md, R.t2map_dirname, "p1", "gaussian_rician")
+    path = os.path.join(bids, str(d["csv_name"]))
+    got = pd.read_csv(path)
+    assert list(got.columns) == list(want.columns)
+    assert list(got["id"]) == list(want["id"]) and list(got["trueT2"]) == list(want["trueT2"])
+    for col in ("meanT2", "stdT2", "meanK", "stdK", "meanC", "stdC"):
+        a, b = got[col].to_numpy(), want[col].to_numpy()
+        assert np.all(a.astype(np.float32).astype(np.float64) == a)  # float32-valued, as the reference's
+        assert np.allclose(a, b, rtol=4e-6, atol=0), (col, a, b)
+    os.remove(path)
+    # (2) the whole pipeline
+    fit, fit_params = "gaussian_rician", t2.fit_table("gaussian_rician", True)
+    R.process_t2maps(md, bids, [int(t) for t in te], fit, fit_params, True, True, True, True, False, "p1")
+    assert sorted(os.path.relpath(p, bids) for p in sitk.written) == sorted(str(x) for x in d["written"])
+    maps = {os.path.relpath(p, bids).split("_sim-p1_")[1].split("map_")[0]: np.asarray(img.arr) for p, img in sitk.written.items()}
+    outside = (d["label"] == 0) | (d["mask"] == 0)
+    for tag in ("t2", "k", "sigma", "res"):
+        assert np.all(maps[tag][outside] == 0) and np.array_equal(d[tag][outside], maps[tag][outside])
+    inside = ~outside
+    assert np.mean(np.abs(maps["t2"][inside] - d["t2"][inside]) <= T2_TOL_MS) >= 0.9
+    got = pd.read_csv(path)
+    close = np.abs(got["meanT2"].to_numpy() - want["meanT2"].to_numpy()) <= np.maximum(1.0, 0.02 * want["meanT2"].to_numpy())
+    assert close.sum() >= len(close) - 2, (got["meanT2"], want["meanT2"])
