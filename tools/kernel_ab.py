@@ -26,6 +26,8 @@ p.add_argument("--no_prior", action="store_true")
 p.add_argument("--legacy", action="store_true")
 p.add_argument("--extras", action="store_true")
 p.add_argument("--reps", type=int, default=10)
+p.add_argument("--solver", default="lbfgsb", choices=["lbfgsb", "lm", "loglin"])
+p.add_argument("--precision", default="f64", choices=["f64", "f32"])
 a = p.parse_args()
 
 lib = C.CDLL(os.environ.get("T2FIT_LIB") or os.path.join(REPO, "fetal_t2mapping_amd", "lib", "libt2fit_hip.so"))
@@ -39,6 +41,10 @@ assert lib.t2fit_config_default(C.byref(cfg), _abi.MODELS[a.fit], 1) == 0
 cfg.n_te = a.nte
 cfg.no_prior = int(a.no_prior)
 cfg.numpy_legacy = int(a.legacy)
+cfg.solver = _abi.SOLVERS[a.solver]
+cfg.precision = _abi.PRECISIONS[a.precision]
+if a.solver == "lm":
+    cfg.maxiter = 0
 for i, t in enumerate(te):
     cfg.te_ms[i] = float(t)
 out = torch.zeros((4, n), dtype=torch.float32, device=dev)
@@ -61,5 +67,5 @@ h = hashlib.sha256(out.cpu().numpy().tobytes())
 if a.extras:
     h.update(nit.cpu().numpy().tobytes())
     h.update(st.cpu().numpy().tobytes())
-print(f"{a.label}: {a.fit} {'noprior' if a.no_prior else 'prior'}{' legacy' if a.legacy else ''} {shape[0]}x{shape[1]}x{shape[2]}x{a.nte}"
+print(f"{a.label}: {a.solver}{'/' + a.precision if a.solver == 'lm' else ''} {a.fit} {'noprior' if a.no_prior else 'prior'}{' legacy' if a.legacy else ''} {shape[0]}x{shape[1]}x{shape[2]}x{a.nte}"
       f" kernel_ms mean {sum(ks) / len(ks):.3f} min {min(ks):.3f} maps sha256 {h.hexdigest()[:24]}", flush=True)
