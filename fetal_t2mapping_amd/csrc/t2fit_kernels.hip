@@ -344,7 +344,10 @@ template <int MODEL, int NTE = 0, bool GSPLIT = false> struct LbfgsbLane {
   // (two parameters: 240 B of pairs per lane would let ten waves share a CU, but three waves per SIMD means 168
   // registers, 29-45 of the lane's spill to scratch, and 7.28 ms become 7.75: profiles/r02_exp50_2par_three_waves.txt)
   static constexpr int kWaveWgHint = MODEL == T2FIT_MODEL_GAUSSIAN ? T2_WAVE_HINT_2PAR : kWaveHint;
-  static constexpr int kRefillMin = 8;   // measured on MI355X: 1 -> 28.1 ms, 8 -> 26.8 ms, 16 -> 27.6 ms
+  // lanes that must be idle before a wave refills.  Measured on MI355X at eight waves per CU (profiles/
+  // r03_exp6_refill_take.txt), 256^3 x 8 TE: 1 -> 12.48 ms, 4 -> 12.13, 8 -> 12.03, 12 -> 12.20, 16 -> 12.42; the Rician
+  // likelihood, whose evaluation is four times as long (an idle lane costs more): 4 -> 19.77, 8 -> 20.01, 16 -> 20.76
+  static constexpr int kRefillMin = MODEL == T2FIT_MODEL_RICIAN ? 4 : 8;
   static constexpr bool kSplit = true;   // advance() = digest() + begin(): the kernel may batch begin() (T2FIT_PARK_MIN)
   __device__ static void init(Solver& s, const ObjCtx&, const double* x0, const double* lb, const double* ub,
                               double* hist, int hstride, double* ghist) { s.init(x0, lb, ub, hist, hstride, ghist, 64); }
