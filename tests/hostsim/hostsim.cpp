@@ -171,6 +171,22 @@ extern "C" int hostsim_log_i0e4(const double* x, int64_t n, double* out, double*
   return 0;
 }
 
+// i0e through the shared 30-step loop a wave with lanes on both sides of 8 runs (each lane picks its series'
+// coefficients; a single simulated lane never gets there through t2_log_i0e4): groups of four arguments on ONE side
+// of 8 each; out = that loop, ref = the one-value Cephes form.
+extern "C" int hostsim_i0e4_by_lane(const double* x, int64_t n, double* out, double* ref) {
+  for (int64_t v = 0; v < n; ++v) {
+    double ax[4];
+    for (int j = 0; j < 4; ++j) ax[j] = x[4 * v + j] < 0 ? -x[4 * v + j] : x[4 * v + j];
+    const bool lane_small = ax[0] <= 8.0;
+    for (int j = 1; j < 4; ++j)
+      if ((ax[j] <= 8.0) != lane_small) return -1;
+    t2_i0e4_by_lane(ax, lane_small, out + 4 * v);
+    for (int j = 0; j < 4; ++j) ref[4 * v + j] = t2_i0e(x[4 * v + j]);
+  }
+  return 0;
+}
+
 // numpy's add.reduce order as the echo loop of the Rician evaluation accumulates it: terms[i * 4 + j] is item i of row
 // sum j; nte_special != 0 uses the compile-time echo-count form (n must then be 3..8), 0 the run-time form.
 extern "C" int hostsim_rowsums4(const double* terms, int n, int nte_special, double* out) {

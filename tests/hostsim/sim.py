@@ -116,6 +116,16 @@ def log_i0e4(x):
     return out, ref
 
 
+def i0e4_by_lane(x):
+    """x: (n, 4) float64, each row on one side of 8 -> (the shared 30-step loop, the one-value Cephes form), (n, 4)."""
+    L = lib()
+    x = np.ascontiguousarray(x, np.float64)
+    out, ref = np.empty_like(x), np.empty_like(x)
+    L.hostsim_i0e4_by_lane.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    assert L.hostsim_i0e4_by_lane(x.ctypes.data, len(x), out.ctypes.data, ref.ctypes.data) == 0
+    return out, ref
+
+
 def rowsums4(terms, nte_special):
     """terms: (n, 4) float64 -> the four column sums as the Rician echo loop accumulates them."""
     L = lib()

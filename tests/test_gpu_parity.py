@@ -1412,7 +1412,7 @@ def test_phantom_csv_against_the_references_file(t2, tmp_path):
     from fetal_t2mapping_amd import cli as R
 
     d = np.load(os.path.join(GOLDEN, "phantom_lf_gaussian_rician_fast.npz"))
-    want = pd.read_csv(io.StringIO(str(d["csv_text"])))
+    want = pd.read_csv(io.StringIO(str(d["csv_text"])), float_precision="round_trip")
     bids = str(tmp_path / "projects") + "/"
     te = d["te"]
     rows = []
@@ -1429,7 +1429,7 @@ def test_phantom_csv_against_the_references_file(t2, tmp_path):
     id_, gt_ = R.set_phantom_gt(True)
     R.save_phantom_csv(d["t2"], d["k"], d["sigma"], d["label"], id_, gt_, bids, md, R.t2map_dirname, "p1", "gaussian_rician")
     path = os.path.join(bids, str(d["csv_name"]))
-    got = pd.read_csv(path)
+    got = pd.read_csv(path, float_precision="round_trip")
     assert list(got.columns) == list(want.columns)
     assert list(got["id"]) == list(want["id"]) and list(got["trueT2"]) == list(want["trueT2"])
     for col in ("meanT2", "stdT2", "meanK", "stdK", "meanC", "stdC"):
@@ -1447,6 +1447,6 @@ def test_phantom_csv_against_the_references_file(t2, tmp_path):
         assert np.all(maps[tag][outside] == 0) and np.array_equal(d[tag][outside], maps[tag][outside])
     inside = ~outside
     assert np.mean(np.abs(maps["t2"][inside] - d["t2"][inside]) <= T2_TOL_MS) >= 0.9
-    got = pd.read_csv(path)
+    got = pd.read_csv(path, float_precision="round_trip")
     close = np.abs(got["meanT2"].to_numpy() - want["meanT2"].to_numpy()) <= np.maximum(1.0, 0.02 * want["meanT2"].to_numpy())
     assert close.sum() >= len(close) - 2, (got["meanT2"], want["meanT2"])

@@ -219,6 +219,24 @@ def test_log_i0e_four_wide_loop_equals_the_cephes_form():
     assert np.array_equal(nan_out, nan_ref, equal_nan=True) and np.isnan(nan_out[0, 0])
 
 
+def test_i0e_shared_loop_equals_the_cephes_form():
+    """t2_i0e4_by_lane -- the 30-step loop a wave runs when some of its lanes need the [0, 8] series and others the
+    (8, inf) one, each lane picking its own series' coefficient (the (8, inf) table behind five zero steps) -- against
+    the one-value Cephes form, bit for bit, for rows on either side, at the boundary and at the extremes; scipy to 1e-14."""
+    from scipy.special import i0e
+
+    rng = np.random.default_rng(12)
+    lo = rng.uniform(0, 8, (800, 4))
+    hi = np.concatenate([rng.uniform(8, 50, (400, 4)), 10.0 ** rng.uniform(1, 8, (400, 4))])
+    hi[hi <= 8.0] = 9.0
+    edge = np.array([[0.0, 8.0, 7.999999999, 1e-300], [np.nextafter(8.0, 9.0), 8.5, 1e300, 1e10], [-3.0, -0.0, -8.0, 2.5],
+                     [-9.0, -1e5, 40.0, 8.000001]])
+    x = np.concatenate([lo, hi, edge])
+    out, ref = sim.i0e4_by_lane(x)
+    assert np.array_equal(out, ref)
+    assert np.allclose(out, i0e(x), rtol=1e-14, atol=0)
+
+
 @pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 8, 9, 11, 15, 16, 17, 24, 31, 32])
 def test_echo_loop_row_sums_are_numpys(n):
     """RowSums4 fed item by item == np.sum of each column, bit for bit (numpy's pairwise order: left to right below
