@@ -13,9 +13,9 @@ Same flags, metadata CSVs, input/output file names and maps as the reference
 (run_t2mapping.py:483-576, utils/metadata_utils.py, utils/qmri_utils.py:13-33,
 utils/t2map_utils.py:18-59); the voxel loop (:411-461) is one call into the HIP library.  NIfTI I/O
 stays SimpleITK on the host, as in the reference (nifti.py stands in where SimpleITK is not installed).
-The convergence-study figures (:465-468) are written on request (--plots, convergence.py).  Not carried
-over: the hard-coded ``prj-00X`` CSV lists of the authors' lab (utils/metadata_utils.py:19-85) -- pass
-the CSV names instead.
+The convergence-study figures (:465-468) are written on request (--plots, convergence.py).  ``--csv prj-004``
+(prj-003, prj-002) stands for the session logs of that project of the reference's paper, as in
+utils/metadata_utils.py:19-85.
 """
 from __future__ import annotations
 
@@ -153,13 +153,51 @@ def get_img_path(bids_path, acq, type: str = "anat"):
     return os.path.join(bids_path, *dirs, "_".join(stem))
 
 
+# `--csv prj-00X` instead of file names: the session logs of the three projects of the reference's paper
+# (utils/metadata_utils.py:19-85), keyed by (project, low_field).  Data, not logic: the file names as the reference lists them
+# (entries it has commented out are left out here too).  None: the reference has no such data and exits.
+_PROJECT_LOGS = {
+    ("prj-004", True): "2024083017_17510000 2024090320_55420000 2024090618_37050000 2024090811_14320000 2024091017_53530000_1 "
+                       "2024091017_53530000_2 2024091020_45220000 2024091320_23400000 2024091321_22550000 2024091322_27490000 "
+                       "2024092720_10110000 2024092719_10310000 2024102120_48480000",
+    ("prj-004", False): "2024083019_26300000 2024090322_28560000 2024090619_26370000 2024090812_21470000 2024091021_57280000 "
+                        "2024091319_13240000 2024091318_13560000 2024092721_25410000 2024102616_18560000 2024102122_28450000",
+    ("prj-003", True): "20240806_30540000_1",
+    ("prj-003", False): None,
+    ("prj-002", True): "20240527_095111_2",
+    ("prj-002", False): "20240609_50140000_2",
+}
+_PROJECT_BANNERS = {
+    "prj-004": ["PRJ-004 - In vivo adult brain data acquired using the head coil"],
+    "prj-003": ["PRJ-003 - In vitro NIST Phantom data acquired using the abdominal coil M",
+                "Notes: only data selected for paper submission are processed."],
+    "prj-002": ["PRJ-002 - In vitro NIST Phantom data acquired using the head coil.",
+                "Notes: only data selected for paper submission are processed."],
+}
+
+
+def project_csvs(project: str, low_field: bool):
+    """utils/metadata_utils.py:19-85 (`prj_004` / `prj_003` / `prj_002`): the CSV list a project name stands for."""
+    logs = _PROJECT_LOGS[(project, bool(low_field))]
+    if logs is None:
+        print("Error: no data to process yet at 1.5 T.")
+        raise SystemExit(1)
+    return [name + ".csv" for name in logs.split()]
+
+
 def set_metadata(csv_path, csvs, low_field):
-    """utils/metadata_utils.py:92-125: concatenate the session log CSVs into one DataFrame."""
+    """utils/metadata_utils.py:92-125: concatenate the session log CSVs into one DataFrame; `--csv prj-004` (or
+    prj-003 / prj-002) stands for that project's list of logs, with the reference's banner."""
     import pandas as pd
 
-    if ".csv" not in csvs[0].lower():
-        print(f"Error: {csvs} is not a valid metadata log file (the reference's hard-coded prj-00X file "
-              "lists are not carried over; pass the CSV names).")
+    if csvs[0] in _PROJECT_BANNERS:
+        lines = _PROJECT_BANNERS[csvs[0]]
+        rule = "*" * max(len(ln) for ln in lines)
+        print("\n".join([rule] + lines + [rule]))
+        csvs = project_csvs(csvs[0], low_field)
+    elif ".csv" not in csvs[0].lower():
+        print(f"Error: {csvs} is not a valid metadata log file nor a valid project to process (only prj-002, prj-003 and "
+              "prj-004 metadata can be processed all at once.)")
         raise SystemExit(1)
     return pd.concat([pd.read_csv(os.path.join(csv_path, c)) for c in csvs])
 

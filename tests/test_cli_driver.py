@@ -158,3 +158,26 @@ def test_phantom_csv_text_equals_the_references_file():
     got = R.phantom_frame(stats64, id_, gt_)
     want = R.phantom_frame(stats, id_, gt_)
     assert np.allclose(got["meanT2"], want["meanT2"], rtol=3e-7, atol=0) and np.allclose(got["stdT2"], want["stdT2"], rtol=2e-6, atol=0)
+
+
+def test_project_shortcuts_of_the_csv_flag(tmp_path, capsys):
+    """`--csv prj-004` (prj-003, prj-002) stands for that project's session logs (utils/metadata_utils.py:19-85,96-113):
+    13 low-field / 10 high-field logs for prj-004, one each for the phantom projects, prj-003 at 1.5 T exits like the
+    reference; the logs are concatenated in list order, and anything that is neither a project nor a .csv name exits."""
+    import pandas as pd
+
+    from fetal_t2mapping_amd import cli as R
+
+    assert len(R.project_csvs("prj-004", True)) == 13 and len(R.project_csvs("prj-004", False)) == 10
+    assert R.project_csvs("prj-004", True)[0] == "2024083017_17510000.csv" and R.project_csvs("prj-004", False)[-1] == "2024102122_28450000.csv"
+    assert R.project_csvs("prj-003", True) == ["20240806_30540000_1.csv"]
+    assert R.project_csvs("prj-002", True) == ["20240527_095111_2.csv"] and R.project_csvs("prj-002", False) == ["20240609_50140000_2.csv"]
+    with pytest.raises(SystemExit):
+        R.project_csvs("prj-003", False)
+    for i, name in enumerate(R.project_csvs("prj-004", False)):
+        pd.DataFrame([{"prj": "prj-004", "sub": f"sub-{i:03d}", "EchoTime": 0.114}]).to_csv(tmp_path / name, index=False)
+    md = R.set_metadata(str(tmp_path), ["prj-004"], False)
+    assert list(md["sub"]) == [f"sub-{i:03d}" for i in range(10)]
+    assert "PRJ-004 - In vivo adult brain data acquired using the head coil" in capsys.readouterr().out
+    with pytest.raises(SystemExit):
+        R.set_metadata(str(tmp_path), ["prj-005"], True)
