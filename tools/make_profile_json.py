@@ -10,7 +10,7 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-KEYS = {"lbfgsb": "gaussian_rician/lbfgsb/f64/256x256x256x8", "lmf32": "gaussian_rician/lm/f32/256x256x256x8",
+KEYS = {"lbfgsb": "gaussian_rician/lbfgsb/f64/256x256x256x8", "rician": "rician/lbfgsb/f64/180x256x256x6", "lmf32": "gaussian_rician/lm/f32/256x256x256x8",
         "lmf64": "gaussian_rician/lm/f64/256x256x256x8", "loglin": "gaussian/loglin/f64/256x256x256x8"}
 
 
