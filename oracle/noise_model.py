@@ -17,8 +17,12 @@ from scipy.special import i0e
 EPS = np.finfo(float).eps
 
 
-def perturbed_objectives(rng):
-    """{mode: objective(p, te, y)}: run_t2mapping.py:141-177 with exp, log and i0e jittered by one ulp (rng)."""
+def perturbed_objectives(rng, numpy_legacy=False, y_row=None):
+    """{mode: objective(p, te, y)}: run_t2mapping.py:141-177 with exp, log and i0e jittered by one ulp (rng).
+    ``numpy_legacy`` (with ``y_row``, the float32 samples of the one voxel this objective will be used for): the rician
+    objective as numpy < 2 evaluates it -- ``np.log(signal) - np.log(sigma**2)`` in float32 (oracle._obj_rician_legacy) --
+    with the float32 ``np.log(signal)`` moved by at most one float32 ulp ONCE for the voxel (another libm gives another,
+    but always the same, value) and the float64 functions jittered per call as before."""
     def jitter(v):
         return v * (1 + EPS * rng.integers(-1, 2, size=np.shape(v)))
 
@@ -42,6 +46,20 @@ def perturbed_objectives(rng):
         return -np.sum((jitter(np.log(y)) - jitter(np.log(s ** 2))) - (y ** 2 + m ** 2) / (2 * s ** 2)
                        + (np.abs(x) + jitter(np.log(jitter(i0e(x))))))
 
+    if numpy_legacy:
+        with np.errstate(all="ignore"):
+            ly = np.log(np.asarray(y_row, np.float32)).astype(np.float32)
+        step = rng.integers(-1, 2, size=ly.shape)
+        ly = np.where(step > 0, np.nextafter(ly, np.float32(np.inf)), np.where(step < 0, np.nextafter(ly, np.float32(-np.inf)), ly)).astype(np.float32)
+
+        def rician_legacy(p, te, y):
+            k, t2, s = p
+            m = k * pexp(-te / t2)
+            x = (m * y) / (s ** 2)
+            a = ly - np.float32(jitter(np.log(s ** 2)))  # float32 array - float32 scalar: float32 under either numpy
+            return -np.sum(a - (y ** 2 + m ** 2) / (2 * s ** 2) + (np.abs(x) + jitter(np.log(jitter(i0e(x))))))
+
+        return {"gaussian": gauss, "gaussian_rician": gauss_rician, "rician": rician_legacy}
     return {"gaussian": gauss, "gaussian_rician": gauss_rician, "rician": rician}
 
 
@@ -52,12 +70,16 @@ def perturbed_fit_rows(args):
 
     from . import t2fit_oracle as O
 
-    idx, fit, low_field, prior, te, rows, seed = args
-    fun = perturbed_objectives(np.random.default_rng(seed))[fit]
+    idx, fit, low_field, prior, te, rows, seed = args[:7]
+    legacy = len(args) > 7 and bool(args[7])
+    rng = np.random.default_rng(seed)
+    fun = None if legacy else perturbed_objectives(rng)[fit]
     out = []
     for v in idx:
         fp = O.fit_table(fit, low_field)
         lb, ub = O.voxel_bounds(fp, rows[v, 0], prior)
+        if legacy:
+            fun = perturbed_objectives(rng, True, rows[v])[fit]
         with np.errstate(all="ignore"):
             r = minimize(fun, fp["initial_guess"], args=(te, np.array(rows[v])), method="L-BFGS-B",
                          bounds=list(zip(lb, ub)), options=fp["options"], jac=False)
@@ -67,14 +89,15 @@ def perturbed_fit_rows(args):
 
 def reference_fit_rows(args):
     """Pool worker: the unperturbed reference-equivalent fit (oracle.fit_voxel) of rows ``idx``.
-    ``args = (idx, fit, low_field, prior, te, rows)`` -> list of (x, nit, success)."""
+    ``args = (idx, fit, low_field, prior, te, rows[, numpy_legacy])`` -> list of (x, nit, success)."""
     from . import t2fit_oracle as O
 
-    idx, fit, low_field, prior, te, rows = args
+    idx, fit, low_field, prior, te, rows = args[:6]
+    legacy = len(args) > 6 and bool(args[6])
     fp = O.fit_table(fit, low_field)
     out = []
     for v in idx:
         with np.errstate(all="ignore"):
-            x, ok, nit, f, _ = O.fit_voxel(int(v), fit, fp, te, rows, prior, False, want_trace=False)
+            x, ok, nit, f, _ = O.fit_voxel(int(v), fit, fp, te, rows, prior, False, want_trace=False, numpy_legacy=legacy)
         out.append((x, nit, ok))
     return out

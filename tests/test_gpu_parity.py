@@ -417,8 +417,9 @@ def test_residual_map_frozen_stack(t2, name):
 # parity at scale: 20 000 voxels per configuration against the live oracle on the box's host cores
 # ---------------------------------------------------------------------------------------------
 AT_SCALE_N = 20000
-AT_SCALE_CONFIGS = [("gaussian", True), ("gaussian", False), ("gaussian_rician", True), ("gaussian_rician", False),
-                    ("rician", True)]
+# (fit, prior, numpy_legacy): the last one is the rician objective as the reference's frozen numpy 1.26 evaluates it
+AT_SCALE_CONFIGS = [("gaussian", True, False), ("gaussian", False, False), ("gaussian_rician", True, False),
+                    ("gaussian_rician", False, False), ("rician", True, False), ("rician", True, True)]
 
 
 @pytest.fixture(scope="module")
@@ -436,31 +437,33 @@ def at_scale_reference():
     chunks = [c for c in np.array_split(np.arange(len(rows)), cores * 4) if len(c)]
     ref = {}
     with mp.get_context("spawn").Pool(cores) as pool:
-        for fit, prior in AT_SCALE_CONFIGS:
-            plain = [r for part in pool.map(reference_fit_rows, [(c, fit, True, prior, te, rows) for c in chunks])
+        for fit, prior, legacy in AT_SCALE_CONFIGS:
+            plain = [r for part in pool.map(reference_fit_rows, [(c, fit, True, prior, te, rows, legacy) for c in chunks])
                      for r in part]
-            pert = [r for part in pool.map(perturbed_fit_rows, [(c, fit, True, prior, te, rows, 7 + i)
+            pert = [r for part in pool.map(perturbed_fit_rows, [(c, fit, True, prior, te, rows, 7 + i, legacy)
                                                                 for i, c in enumerate(chunks)]) for r in part]
-            ref[(fit, prior)] = (np.array([r[0] for r in plain]), np.array([r[2] for r in plain]),
+            ref[(fit, prior, legacy)] = (np.array([r[0] for r in plain]), np.array([r[2] for r in plain]),
                                  np.array([r[1] for r in plain]), np.array([r[0] for r in pert]),
                                  np.array([r[2] for r in pert]))
     return rows, te, ref
 
 
-@pytest.mark.parametrize("fit,prior", AT_SCALE_CONFIGS, ids=[f"{f}-{'prior' if p else 'noprior'}" for f, p in AT_SCALE_CONFIGS])
-def test_lbfgsb_parity_at_scale(t2, at_scale_reference, fit, prior):
+@pytest.mark.parametrize("fit,prior,legacy", AT_SCALE_CONFIGS,
+                         ids=[f"{f}-{'prior' if p else 'noprior'}{'-numpy1' if lg else ''}" for f, p, lg in AT_SCALE_CONFIGS])
+def test_lbfgsb_parity_at_scale(t2, at_scale_reference, fit, prior, legacy):
     """HIP lane solver against the live oracle on 20 000 voxels of the bench distribution (8 TE), measured with the
     yardstick of what the reference reaches against ITSELF when its exp / log / i0e move by one ulp:
       * fraction of voxels with T2 within 1 ms: HIP >= yardstick - 0.01
       * median, 90th and 99th percentile of |dT2|: HIP <= 1.2 x yardstick (+ 1e-3 ms)
       * `success` equal on >= 99.9 %; iteration count equal at least as often as the yardstick - 0.01."""
     rows, te, ref = at_scale_reference
-    x_ref, ok_ref, nit_ref, x_pert, ok_pert = ref[(fit, prior)]
-    x, ok, nit, fun, st = t2.fit_voxels(np.arange(len(rows)), fit, t2.fit_table(fit, True), te, rows, prior, False)
+    x_ref, ok_ref, nit_ref, x_pert, ok_pert = ref[(fit, prior, legacy)]
+    x, ok, nit, fun, st = t2.fit_voxels(np.arange(len(rows)), fit, t2.fit_table(fit, True), te, rows, prior, False,
+                                        numpy_legacy=legacy)
     dt = np.abs(x[:, 1] - x_ref[:, 1])
     dtp = np.abs(x_pert[:, 1] - x_ref[:, 1])
     frac, frac_p = float(np.mean(dt <= T2_TOL_MS)), float(np.mean(dtp <= T2_TOL_MS))
-    report = {"config": f"{fit}/{'prior' if prior else 'noprior'}", "n": len(rows), "hip_within_1ms": frac,
+    report = {"config": f"{fit}/{'prior' if prior else 'noprior'}{'/numpy_legacy' if legacy else ''}", "n": len(rows), "hip_within_1ms": frac,
               "reference_vs_itself_within_1ms": frac_p, "success_equal": float(np.mean(ok == ok_ref)),
               "nit_equal": float(np.mean(nit == nit_ref))}
     for q in (50, 90, 99):
