@@ -310,7 +310,12 @@ T2_TABLE double t2_i0e_Bp[30] = {
 // the other one, so practically every wave needs both: run one after the other (for all lanes) that is 55 steps of
 // 12 float64 operations; here it is 30 steps of 12 + a select.  Every lane performs exactly the operations of its own
 // series (the padding steps of t2_i0e_Bp leave +0): same bits as t2_i0e.
+#ifndef T2_I0E_CHUNK
+#define T2_I0E_CHUNK 5  // coefficients per trip of the shared loop (30 = 2 x 15 = 3 x 10 = 5 x 6 = 6 x 5 = 10 x 3)
+#endif
 T2_HD void t2_i0e4_by_lane(const double* ax, bool lane_small, double* r) {
+  constexpr int K = T2_I0E_CHUNK;
+  static_assert(30 % K == 0, "the shared loop walks both 30-entry tables in whole chunks");
   double z[4], b0[4], b1[4], b2[4];
   T2_UNROLL
   for (int j = 0; j < 4; ++j) {
@@ -318,20 +323,20 @@ T2_HD void t2_i0e4_by_lane(const double* ax, bool lane_small, double* r) {
     z[j] = lane_small ? za : zb;
     b0[j] = 0.0; b1[j] = 0.0; b2[j] = 0.0;
   }
-  double an[5], bn[5];
+  double an[K], bn[K];
   T2_UNROLL
-  for (int q = 0; q < 5; ++q) { an[q] = t2_i0e_A[q]; bn[q] = t2_i0e_Bp[q]; }
+  for (int q = 0; q < K; ++q) { an[q] = t2_i0e_A[q]; bn[q] = t2_i0e_Bp[q]; }
   T2_NOUNROLL
-  for (int it = 0; it < 6; ++it) {
-    double cc[5];
+  for (int it = 0; it < 30 / K; ++it) {
+    double cc[K];
     T2_UNROLL
-    for (int q = 0; q < 5; ++q) cc[q] = lane_small ? an[q] : bn[q];
-    if (it + 1 < 6) {
+    for (int q = 0; q < K; ++q) cc[q] = lane_small ? an[q] : bn[q];
+    if (it + 1 < 30 / K) {
       T2_UNROLL
-      for (int q = 0; q < 5; ++q) { an[q] = t2_i0e_A[(it + 1) * 5 + q]; bn[q] = t2_i0e_Bp[(it + 1) * 5 + q]; }
+      for (int q = 0; q < K; ++q) { an[q] = t2_i0e_A[(it + 1) * K + q]; bn[q] = t2_i0e_Bp[(it + 1) * K + q]; }
     }
     T2_UNROLL
-    for (int q = 0; q < 5; ++q) {
+    for (int q = 0; q < K; ++q) {
       T2_UNROLL
       for (int j = 0; j < 4; ++j) {
         b2[j] = b1[j];

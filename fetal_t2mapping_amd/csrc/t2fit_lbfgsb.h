@@ -608,18 +608,19 @@ struct Lbfgsb {
     double rp[N], yp[N];  // rp[1..N-1]: the current pair's ratios s_i / s_0 (rp[0] unused: it is the implicit 1)
     T2_UNROLL
     for (int i = 0; i < N; ++i) { rp[i] = 0.0; yp[i] = 0.0; }
+    int q = head;  // ring slot of pair p, stepped along instead of (head + p) % M per pair
     if (col > 0) {
-      const int q0 = slot_of(0);
       T2_UNROLL
-      for (int i = 1; i < N; ++i) rp[i] = hratio(q0, i - 1);
+      for (int i = 1; i < N; ++i) rp[i] = hratio(q, i - 1);
       T2_UNROLL
-      for (int i = 0; i < N; ++i) yp[i] = hy(q0, i);
+      for (int i = 0; i < N; ++i) yp[i] = hy(q, i);
     }
     T2_UNROLL
     for (int p = 0; p < M; ++p) {
       if (p >= col) continue;
       double rn[N], yn[N];
-      const int qn = slot_of(p + 1 < col ? p + 1 : p);
+      const int qn = p + 1 < col ? (q + 1 == M ? 0 : q + 1) : q;
+      q = qn;
       rn[0] = 0.0;
       T2_UNROLL
       for (int i = 1; i < N; ++i) rn[i] = hratio(qn, i - 1);
