@@ -1453,3 +1453,48 @@ def test_phantom_csv_against_the_references_file(t2, tmp_path):
     got = pd.read_csv(path, float_precision="round_trip")
     close = np.abs(got["meanT2"].to_numpy() - want["meanT2"].to_numpy()) <= np.maximum(1.0, 0.02 * want["meanT2"].to_numpy())
     assert close.sum() >= len(close) - 2, (got["meanT2"], want["meanT2"])
+
+
+def test_cli_gpus_2_shared_volume_two_ranks_one_gpu(t2, tmp_path):
+    """`python -m fetal_t2mapping_amd.cli ... --gpus 2` end to end on real .nii.gz files with ONE subject, so the volume is
+    shared: the command relaunches itself under torch.distributed.run, each rank decodes its echo files only, shares are
+    swapped, both ranks fit on this box's one GPU (collectives through gloo: T2FIT_CLI_BACKEND -- a rehearsal, RCCL needs
+    one GPU per rank), maps / status are gathered and rank 0 writes.  The four maps on disk equal a single-process fit of
+    the same files bit for bit; the --no_prior objective leaves voxels that do not converge, and their true count is
+    printed by both ranks; --plots draws its figures from rows fetched from the rank that holds each echo."""
+    import subprocess
+    import sys
+
+    import pandas as pd
+
+    from fetal_t2mapping_amd import cli as R
+    from fetal_t2mapping_amd import nifti, synth
+
+    echoes, mask, te = synth.brain_volume((6, 40, 150), 3, seed=21, low_field=True)   # 36 000 voxels: three chunks, ragged
+    echoes[1, 3, 20, 70] = np.inf                                                     # one voxel the fit refuses (status 3)
+    mask[3, 20, 70] = 1
+    root = str(tmp_path)
+    bids = os.path.join(root, "projects") + "/"
+    os.makedirs(os.path.join(bids, "prj-902"))
+    os.makedirs(os.path.join(root, "dicom", "logs"))
+    rows = []
+    for i, t in enumerate(te):
+        acq = {"prj": "prj-902", "sub": "sub-001", "ses": "ses-01", "run": f"run-{i + 1:02d}", "EchoTime": t / 1000.0,
+               "CoilString": "HeadNeck"}
+        rows.append(acq)
+        for arr, dirname in ((echoes[i], R.recon_dirname), (mask, R.mask_dirname)):
+            nifti.WriteImage(nifti.GetImageFromArray(arr), R.get_img_path(bids, acq, dirname).replace(" ", ""))
+    pd.DataFrame(rows).to_csv(os.path.join(root, "dicom", "logs", "log.csv"), index=False)
+    repo = os.path.dirname(os.path.dirname(GOLDEN))
+    env = dict(os.environ, T2FIT_CLI_BACKEND="gloo", MASTER_ADDR="127.0.0.1", PYTHONPATH=repo)
+    cmd = [sys.executable, "-m", "fetal_t2mapping_amd.cli", "--path", root, "--csv", "log.csv", "--in_vivo", "--gaussian_rician", "--lf",
+           "--sim", "g2", "--gpus", "2", "--plots", "--plot_seed", "4", "--TEs"] + [str(int(t)) for t in te]
+    out = subprocess.run(cmd, check=True, capture_output=True, text=True, env=env, timeout=600, cwd=repo)
+    want = t2.fit_volume(echoes, mask, te, "gaussian_rician", t2.fit_table("gaussian_rician", True), extras=True)
+    n_fail = int(np.sum((want.status != 1) & (want.status != 0)))
+    assert n_fail >= 1 and out.stdout.count(f"FAIL : Optimization failed for {n_fail} voxels") == 2, out.stdout[-2000:]
+    out_dir = os.path.join(bids, "prj-902", "derivatives", R.t2map_dirname, "sub-001", "ses-01", "anat")
+    for m in ("t2", "k", "sigma", "res"):
+        img = nifti.ReadImage(os.path.join(out_dir, f"sub-001_ses-01_recon_1mm_sim-g2_{m}map_ada-gaussian_rician.nii.gz"))
+        assert np.array_equal(img.arr, getattr(want, m), equal_nan=True), m
+    assert len(os.listdir(os.path.join(bids, "prj-902", "ada", "convergence_analysis"))) == 3
