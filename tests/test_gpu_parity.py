@@ -954,6 +954,10 @@ def test_large_volume_kernels_equal_the_small_volume_kernel(t2, fit, n_te, prior
     echoes, mask, te = synth.brain_volume_torch(shape, n_te, synth.SEED_BASE + 11, dev)
     n = shape[0] * shape[1] * shape[2] - 37  # ragged: the last chunk of 64 is cut
     echoes = echoes[:, :n].contiguous()
+    if fit == "rician":  # samples the likelihood cannot digest (log 0, log of a negative number: the reference's objective is
+        echoes[:, 5::997] = 0.0   # NaN from the first evaluation on and scipy returns the start point, success False)
+        echoes[0, 7::991] = -3.0
+        echoes[n_te - 1, 11::983] = 0.0
     table = t2.fit_table(fit, True)
     if norm:  # signals in (0, 1]: a table on that scale
         table = dict(table)
