@@ -230,6 +230,13 @@ T2_TABLE double t2_i0e_B[25] = {
     2.89137052083475648297E-6,   6.88975834691682398426E-5,   3.36911647825569408990E-3,
     8.04490411014108831608E-1};
 
+// Cephes' recurrence as its C source evaluates it without fused multiply-add (scipy's wheels: baseline x86-64): a product, a
+// difference, a sum.  -DT2_I0E_FMA (experiment only, tools/experiments/r03_exp13.sh) fuses the product into the difference.
+#if defined(T2_I0E_FMA)
+#define T2_CLENSHAW(z, b1, b2, c) (fma(z, b1, -(b2)) + (c))
+#else
+#define T2_CLENSHAW(z, b1, b2, c) ((z) * (b1) - (b2) + (c))
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define T2_NOUNROLL _Pragma("nounroll")
 #define T2_WAVE_ANY(p) (__ballot(p) != 0ull)
@@ -282,7 +289,7 @@ T2_HD void t2_chbevl4(const double* z, const double* tab, int chunks, double* ou
       for (int j = 0; j < 4; ++j) {
         b2[j] = b1[j];
         b1[j] = b0[j];
-        b0[j] = z[j] * b1[j] - b2[j] + cc[q];
+        b0[j] = T2_CLENSHAW(z[j], b1[j], b2[j], cc[q]);
       }
     }
   }
@@ -341,7 +348,7 @@ T2_HD void t2_i0e4_by_lane(const double* ax, bool lane_small, double* r) {
       for (int j = 0; j < 4; ++j) {
         b2[j] = b1[j];
         b1[j] = b0[j];
-        b0[j] = z[j] * b1[j] - b2[j] + cc[q];
+        b0[j] = T2_CLENSHAW(z[j], b1[j], b2[j], cc[q]);
       }
     }
   }
@@ -352,6 +359,40 @@ T2_HD void t2_i0e4_by_lane(const double* ax, bool lane_small, double* r) {
     r[j] = lane_small ? ra : rb;
   }
 }
+
+// log() of i0e's values (positive normal numbers in (0, 1]) the way fdlibm's __ieee754_log computes it: argument reduction to
+// [sqrt(2)/2, sqrt(2)), s = f / (2 + f), a degree-7 polynomial in s^2, the exponent times ln 2 in two pieces; error below
+// 1 ulp, about 35 instructions.  The device library's log is a double-double evaluation of about 75 instructions, and the
+// Rician likelihood takes four logs per echo and evaluation: 30 % of its evaluation.  Neither is the reference's log (numpy's)
+// bit for bit -- log is one of the functions the one-ulp yardstick perturbs -- and measured on 20 000 voxels against the
+// live oracle the leaner one agrees at least as often: T2 within 1 ms 98.31 % against 98.26 %, iteration count equal 99.37 %
+// against 99.30 %, the numpy_legacy form 99.90 % both, the stable sets of the twelve rician fixtures 0 of 809 rows off both
+// (profiles/r03_exp12_lean_log.txt); kernel 18.07 -> 16.20 ms at 256 x 256 x 180 x 6 TE.  -DT2_OCML_LOG restores the library call.
+T2_HD double t2_log_lean(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int e = __builtin_amdgcn_frexp_exp(x);           // x = m 2^e, m in [0.5, 1)
+  double m = __builtin_amdgcn_frexp_mant(x);
+#else
+  int e;
+  double m = frexp(x, &e);
+#endif
+  const bool low = m < 0x1.6a09e667f3bcdp-1;       // sqrt(2) / 2
+  m = low ? m + m : m;
+  e = low ? e - 1 : e;
+  const double f = m - 1.0, k = (double)e;
+  const double s = t2_fdiv(f, 2.0 + f);
+  const double z = s * s, w = z * z;
+  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                            6.666666666666735130e-01);
+  const double R = t2 + t1, hfsq = 0.5 * f * f;
+  return fma(k, 6.93147180369123816490e-01, -((hfsq - fma(s, hfsq + R, k * 1.90821492927058770002e-10)) - f));
+}
+#if defined(T2_OCML_LOG)
+#define T2_LOG_I0E(v) t2_log(v)
+#else
+#define T2_LOG_I0E(v) t2_log_lean(v)
+#endif
 
 // log(i0e(x)) for four arguments (the four points of one forward-difference evaluation at one echo: they differ by
 // 1e-8 relative, so a lane's four arguments need the same series except within 1e-8 of the boundary 8).  Branches are
@@ -394,7 +435,7 @@ T2_HD void t2_log_i0e4(const double* x, double* out) {
     for (int j = 0; j < 4; ++j) r[j] = small[j] ? ra[j] : rb[j];
   }
   T2_UNROLL
-  for (int j = 0; j < 4; ++j) out[j] = t2_log(r[j]);
+  for (int j = 0; j < 4; ++j) out[j] = T2_LOG_I0E(r[j]);
 }
 
 // ---- objective values exactly in the reference's operation order (float64) ---------------------

@@ -101,7 +101,7 @@ template <> struct ObjTerm<T2FIT_MODEL_RICIAN> {
     const double xx = t2_fdiv(m * (double)yf, s2);
     const double a = rician_log_term(logf(yf), ls2, legacy);
     const double b = t2_fdiv((double)(yf * yf) + m * m, 2.0 * s2);
-    const double d = (xx < 0 ? -xx : xx) + t2_log(t2_i0e(xx));
+    const double d = (xx < 0 ? -xx : xx) + T2_LOG_I0E(t2_i0e(xx));
     return (a - b) + d;
   }
   T2_HD double finish(const ObjCtx&, double s) const { return -s; }

@@ -166,7 +166,7 @@ extern "C" int hostsim_pair_roundtrip(int dim, const double* s_in, int64_t n, do
 extern "C" int hostsim_log_i0e4(const double* x, int64_t n, double* out, double* ref) {
   for (int64_t v = 0; v < n; ++v) {
     t2_log_i0e4(x + 4 * v, out + 4 * v);
-    for (int j = 0; j < 4; ++j) ref[4 * v + j] = t2_log(t2_i0e(x[4 * v + j]));
+    for (int j = 0; j < 4; ++j) ref[4 * v + j] = T2_LOG_I0E(t2_i0e(x[4 * v + j]));
   }
   return 0;
 }
@@ -244,4 +244,11 @@ extern "C" int hostsim_rician_eval(const t2fit_config* cfg, const float* row, co
     case 8: { Lbfgsb<T2FIT_MODEL_RICIAN, 8> s; run(s); return 0; }
   }
   return -1;
+}
+
+
+// the lane's log() for i0e values (fdlibm's algorithm, t2fit_lane.h) on n positive numbers
+extern "C" int hostsim_log_lean(const double* x, int64_t n, double* out) {
+  for (int64_t v = 0; v < n; ++v) out[v] = t2_log_lean(x[v]);
+  return 0;
 }

@@ -146,3 +146,13 @@ def rician_eval(cfg, row, x, nte_special):
     rc = L.hostsim_rician_eval(C.byref(cfg), row.ctypes.data, x.ctypes.data, int(nte_special), out.ctypes.data, ref.ctypes.data)
     assert rc == 0, rc
     return out, ref[0]
+
+
+def log_lean(x):
+    """The lane's log() for i0e values (fdlibm's algorithm) on positive float64 numbers."""
+    L = lib()
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.empty_like(x)
+    L.hostsim_log_lean.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    assert L.hostsim_log_lean(x.ctypes.data, x.size, out.ctypes.data) == 0
+    return out

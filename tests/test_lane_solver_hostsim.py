@@ -219,6 +219,27 @@ def test_log_i0e_four_wide_loop_equals_the_cephes_form():
     assert np.array_equal(nan_out, nan_ref, equal_nan=True) and np.isnan(nan_out[0, 0])
 
 
+def test_lean_log_is_within_one_ulp():
+    """t2_log_lean (fdlibm's __ieee754_log restated: what the Rician lane applies to i0e's values) against a 50-digit
+    logarithm: below 1 ulp on the range i0e can return ((0, 1]) and far beyond it, exact at 1."""
+    from decimal import Decimal, getcontext
+
+    getcontext().prec = 50
+    rng = np.random.default_rng(13)
+    x = np.concatenate([rng.uniform(0.0, 1.0, 4000), 10.0 ** rng.uniform(-12, 0, 2000), 10.0 ** rng.uniform(0, 12, 500),
+                        1.0 + rng.uniform(-1e-3, 1e-3, 1000), np.array([1.0, 0.5, 2.0, 0.7071067811865476, 1e-300, 1e300])])
+    x = x[x > 0]
+    got = sim.log_lean(x)
+    worst = 0.0
+    for xi, gi in zip(x[::7], got[::7]):  # (Decimal is slow: every seventh point)
+        exact = Decimal(float(xi)).ln()
+        ulp = Decimal(float(np.spacing(abs(gi)))) if gi != 0 else Decimal(5e-324)
+        worst = max(worst, float(abs(Decimal(float(gi)) - exact) / ulp))
+    assert worst < 1.0, worst
+    assert sim.log_lean(np.array([1.0]))[0] == 0.0
+    assert np.allclose(got, np.log(x), rtol=3e-16, atol=3e-19)
+
+
 def test_i0e_shared_loop_equals_the_cephes_form():
     """t2_i0e4_by_lane -- the 30-step loop a wave runs when some of its lanes need the [0, 8] series and others the
     (8, inf) one, each lane picking its own series' coefficient (the (8, inf) table behind five zero steps) -- against
