@@ -1112,7 +1112,10 @@ int launch_fit(const t2fit_config* cfg, const float* echoes, int layout, const u
 #undef T2_LM
     }
 #undef T2_PERSIST
-    if (pe != hipSuccess) return fail(T2FIT_E_HIP, std::string("persistent fit launch: ") + hipGetErrorString(pe));
+    if (pe != hipSuccess) {
+      (void)hipFreeAsync(counter, st);
+      return fail(T2FIT_E_HIP, std::string("persistent fit launch: ") + hipGetErrorString(pe));
+    }
     if (g_timing) T2_HIP(hipEventRecord(g_ev1[g_ev_slot], st));  // the fit kernel ends here; the epilogue pass is a separate, HBM-bound launch
     hipLaunchKernelGGL(residuals_kernel, dim3(grid), dim3(kBlock), lds, st, P, echoes, layout, mask, n_vox,
                        (const float*)dm.t2, (const float*)dm.k, (const float*)dm.sigma, dm.res, dm.r2, dm.se);
