@@ -30,6 +30,8 @@ inline LaneParams make_lane_params(const t2fit_config& c) {
   P.lm_r_x0 = 1.0 / c.x0[1];
   t2_exp_res_coefficients(P.exp_c);
   P.inv_n = 1.0 / c.n_te;
+  P.te_max = 0.0;
+  for (int i = 0; i < c.n_te; ++i) P.te_max = c.te_ms[i] > P.te_max ? c.te_ms[i] : P.te_max;
   P.lbfgsb_tol = (c.ftol / 2.220446049250313e-16) * 2.220446049250313e-16;
   return P;
 }

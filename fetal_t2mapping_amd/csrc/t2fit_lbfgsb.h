@@ -482,11 +482,52 @@ struct Lbfgsb {
       const double k2 = x[0] * x[0], kp2 = x1[0] * x1[0], t2 = x[1], t2p = x1[1];
       const double sg2 = x[N - 1] * x[N - 1], sgp2 = x1[N - 1] * x1[N - 1];
       const double rt2 = t2_rcp_for_div(t2), rt2p = t2_rcp_for_div(t2p);
+      // The four radicands of an echo lie within a few steps' worth of each other: when every displaced point is within
+      // 2^-22 (relative, in the radicand) of the base point -- k and sigma directly, exp(-2 te / T2) through the largest echo time -- the
+      // three displaced square roots start from the base one's reciprocal root (t2_sqrt_near: same bits, 6 instead of 11
+      // instructions).  Decided once per evaluation for the whole wave; a lane at a degenerate point (a zero parameter,
+      // a step that was replaced by the distance to a bound) sends the wave through the independent roots.
+      // (2^-22: the coupled Newton step of t2_sqrt_near then lands 2^-45 from the root and the correction 2^-39 ulp from it;
+      // the reference's steps are 1e-8 on k >= 550, sigma >= 2 and T2 >= 10 ms: 2^-36, 2^-28 and, at 300 ms, 2^-24)
+      const double tol = 0x1p-22;
+      const bool near = 2.0 * lb_abs(dx[0]) <= tol * lb_abs(x[0]) && 2.0 * lb_abs(dx[N - 1]) <= tol * lb_abs(x[N - 1]) &&
+                        2.0 * P.te_max * lb_abs(dx[1]) <= tol * (t2 * t2p);
+      if (T2_WAVE_ANY(!near)) {
+        // the rare way round: independent roots, one echo at a time in a real loop (compact code beside the straight-line
+        // block below, whose registers it must not add to); same operations, same summation order (RowSums4)
+        RowSums4<NTE> sums;
+        sums.init();
+        T2_NOUNROLL
+        for (int i = 0; i < n; ++i) {
+          float yf;
+          if constexpr (NTE > 0) {  // register-resident samples: always read ys[0], rotate by one (see the Rician loop below)
+            yf = ys[0];
+            T2_UNROLL
+            for (int j = 0; j + 1 < NTE; ++j) ys[j] = ys[j + 1];
+            ys[NTE - 1] = yf;
+          } else {
+            yf = c.sample(i);
+          }
+          const double y = (double)yf, te = P.te[i];
+          const double E = t2_exp_core(t2_div_by_rcp(-2.0 * te, t2, rt2)), Ep = t2_exp_core(t2_div_by_rcp(-2.0 * te, t2p, rt2p));
+          const double r0 = y - t2_sqrt_core(k2 * E + sg2), r1 = y - t2_sqrt_core(kp2 * E + sg2);
+          const double r2 = y - t2_sqrt_core(k2 * Ep + sg2), r3 = y - t2_sqrt_core(k2 * E + sgp2);
+          const double tm[4] = {r0 * r0, r1 * r1, r2 * r2, r3 * r3};
+          sums.add(i, n, tm);
+        }
+        f = mean(sums.total(0));
+        g[0] = t2_fdiv(mean(sums.total(1)) - f, dx[0]);
+        g[1] = t2_fdiv(mean(sums.total(2)) - f, dx[1]);
+        g[N - 1] = t2_fdiv(mean(sums.total(3)) - f, dx[N - 1]);
+        return;
+      }
       auto body = [&](int i, auto add) {
         const double y = (double)smp(c, i), te = P.te[i];
         const double E = t2_exp_core(t2_div_by_rcp(-2.0 * te, t2, rt2)), Ep = t2_exp_core(t2_div_by_rcp(-2.0 * te, t2p, rt2p));
-        const double r0 = y - t2_sqrt_core(k2 * E + sg2), r1 = y - t2_sqrt_core(kp2 * E + sg2);
-        const double r2 = y - t2_sqrt_core(k2 * Ep + sg2), r3 = y - t2_sqrt_core(k2 * E + sgp2);
+        double h;
+        const double q0 = t2_sqrt_core_h(k2 * E + sg2, h);
+        const double r0 = y - q0, r1 = y - t2_sqrt_near(kp2 * E + sg2, h);
+        const double r2 = y - t2_sqrt_near(k2 * Ep + sg2, h), r3 = y - t2_sqrt_near(k2 * E + sgp2, h);
         add(r0 * r0, r1 * r1, r2 * r2, r3 * r3);
       };
       static_for<0, 8>([&](auto JC) {

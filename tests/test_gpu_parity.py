@@ -1502,3 +1502,38 @@ def test_cli_gpus_2_shared_volume_two_ranks_one_gpu(t2, tmp_path):
         img = nifti.ReadImage(os.path.join(out_dir, f"sub-001_ses-01_recon_1mm_sim-g2_{m}map_ada-gaussian_rician.nii.gz"))
         assert np.array_equal(img.arr, getattr(want, m), equal_nan=True), m
     assert len(os.listdir(os.path.join(bids, "prj-902", "ada", "convergence_analysis"))) == 3
+
+
+def test_wide_difference_step_takes_the_independent_square_roots(t2):
+    """The 3-parameter least-squares evaluation starts the three displaced square roots of an echo from the base point's
+    reciprocal root when the forward-difference step is small against the parameters (the reference's 1e-8: always), and
+    takes four independent roots in a compact echo loop otherwise -- decided per evaluation for the whole wave
+    (Lbfgsb::eval).  A user table with `eps` = 1e-4 sends every evaluation the second way: against the live oracle (the wide
+    step leaves no forward-difference noise to speak of, so the trajectories agree closely), and large-volume kernel ==
+    generic kernel bit for bit as for the usual step."""
+    import torch
+
+    from fetal_t2mapping_amd import synth
+    from oracle import t2fit_oracle as O
+
+    te = np.linspace(114.0, 299.0, 8)
+    table = dict(t2.fit_table("gaussian_rician", True))
+    table["options"] = dict(table["options"], eps=1e-4)
+    y, _ = synth.voxels(np.random.default_rng(123), te, 240, sigmas=(5.0, 20.0))
+    x, ok, nit, fun, st = t2.fit_voxels(np.arange(len(y)), "gaussian_rician", table, te, y, True, False)
+    ref = [O.fit_voxel(v, "gaussian_rician", table, te, y, True, False, want_trace=False) for v in range(len(y))]
+    xr = np.array([r[0] for r in ref])
+    assert np.mean(np.abs(x[:, 1] - xr[:, 1]) <= T2_TOL_MS) >= 0.98
+    assert np.mean(ok == np.array([r[1] for r in ref])) >= 0.99 and np.mean(nit == np.array([r[2] for r in ref])) >= 0.9
+    dev = torch.device("cuda", 0)
+    shape = (20, 256, 256)
+    echoes, mask, te_v = synth.brain_volume_torch(shape, 8, synth.SEED_BASE + 12, dev)
+    n = shape[0] * shape[1] * shape[2]
+    whole = t2.fit_volume(echoes.reshape(8, 1, 1, n), mask, te_v, "gaussian_rician", table, extras=True)
+    piece = 1 << 19
+    for lo in range(0, n, piece):
+        hi = min(n, lo + piece)
+        part = t2.fit_volume(echoes[:, lo:hi].contiguous().reshape(8, 1, 1, hi - lo), mask[lo:hi].contiguous(), te_v,
+                             "gaussian_rician", table, extras=True)
+        for name in ("t2", "k", "sigma", "res", "nit", "status"):
+            assert _bitwise_equal(getattr(whole, name).reshape(-1)[lo:hi], getattr(part, name).reshape(-1)), (name, lo)
