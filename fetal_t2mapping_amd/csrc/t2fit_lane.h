@@ -107,6 +107,12 @@ T2_HD double t2_rcp_for_div(double b) { return t2_fast_rcp(b); }  // r for t2_di
 T2_HD double t2_fdiv(double a, double b) { return a / b; }
 T2_HD double t2_rcp_for_div(double b) { return 1.0 / b; }
 #endif
+// a / b from r = 1/b (correctly rounded) with one residual correction: the correctly rounded quotient
+// except for rare last-bit cases, at three FMA-class operations instead of an IEEE division sequence
+T2_HD double t2_div_by_rcp(double a, double b, double r) {
+  const double q = a * r;
+  return fma(fma(-q, b, a), r, q);
+}
 T2_HD double t2_rsqrt(double x) { return 1.0 / sqrt(x); }
 // 1 / sqrt(x) to ~1 ulp for x > 0 (v_rsq_f64 seed, two Newton steps), same use as t2_fast_rcp
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -162,14 +168,20 @@ T2_HD double t2_sqrt_core(double x) {
   g = fma(d, h, g);
   return g;
 }
+#else
+T2_HD double t2_exp_core(double x) { return exp(x); }
+T2_HD double t2_sqrt_core(double x) { return sqrt(x); }
+#endif
+
 // The square root of x together with h = 1 / (2 sqrt(x)) (to ~2^-51), and the square root of a value NEAR x from that h:
 // the four radicands of one echo of a forward-difference evaluation differ by the step, parts in 1e8 or less, so the three
 // displaced ones start from the first one's refined reciprocal root (one more coupled Newton step brings g and h to ~1e-15 of
 // the new argument's, then the same residual correction as above) -- 6 instead of 11 instructions each.  Both sequences end in
 // g + (a - g^2) h with g within an ulp and h good to 2^-50: the correctly rounded root, the same bits (Markstein).
-// |a - x| <= 2^-20 x is the caller's business (Lbfgsb::eval checks it once per evaluation).
-T2_HD double t2_sqrt_core_h(double x, double& h_out) {
-  const double y = fmin(__builtin_amdgcn_rsq(x), 1e300);
+// x > 0 and |a - x| <= 2^-20 x are the caller's business (Lbfgsb::eval checks both once per evaluation).
+// The sequences are plain FMA arithmetic (`_seq`, host and device: tests/test_lane_solver_hostsim.py runs them on the CPU
+// from a seed as coarse as the hardware's, against the correctly rounded sqrt); the device entry points feed them v_rsq_f64.
+T2_HD double t2_sqrt_from_seed_seq(double x, double y, double& h_out) {  // y ~ 1 / sqrt(x) to 2^-23 or better, x > 0
   double g = x * y, h = y * 0.5;
   const double r = fma(-h, g, 0.5);
   g = fma(g, r, g);
@@ -181,7 +193,11 @@ T2_HD double t2_sqrt_core_h(double x, double& h_out) {
   h_out = h;
   return g;
 }
-T2_HD double t2_sqrt_near(double a, double h) {
+T2_HD double t2_rsqrt_half_near_seq(double a, double h) {  // 1 / (2 sqrt(a)) from h = 1 / (2 sqrt(x)) of a nearby x
+  const double g = a * (h + h);
+  return fma(h, fma(-h, g, 0.5), h);
+}
+T2_HD double t2_sqrt_near_seq(double a, double h) {
   double g = a * (h + h);
   const double r = fma(-h, g, 0.5);
   g = fma(g, r, g);
@@ -189,11 +205,21 @@ T2_HD double t2_sqrt_near(double a, double h) {
   const double d = fma(-g, g, a);
   return fma(d, hi, g);
 }
+// sqrt(a) from h = 1 / (2 sqrt(a)) good to 2^-50 (the Rician lane keeps only h across its Chebyshev loop)
+T2_HD double t2_sqrt_from_h_seq(double a, double h) {
+  const double g0 = a * (h + h);
+  return fma(fma(-g0, g0, a), h, g0);
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+T2_HD double t2_sqrt_core_h(double x, double& h_out) { return t2_sqrt_from_seed_seq(x, __builtin_amdgcn_rsq(x), h_out); }
+T2_HD double t2_sqrt_near(double a, double h) { return t2_sqrt_near_seq(a, h); }
+T2_HD double t2_rsqrt_half_near(double a, double h) { return t2_rsqrt_half_near_seq(a, h); }
+T2_HD double t2_sqrt_from_h(double a, double h) { return t2_sqrt_from_h_seq(a, h); }
 #else
-T2_HD double t2_exp_core(double x) { return exp(x); }
-T2_HD double t2_sqrt_core(double x) { return sqrt(x); }
-T2_HD double t2_sqrt_core_h(double x, double& h_out) { h_out = 0.0; return sqrt(x); }
+T2_HD double t2_sqrt_core_h(double x, double& h_out) { h_out = 0.5 / sqrt(x); return sqrt(x); }
 T2_HD double t2_sqrt_near(double a, double) { return sqrt(a); }
+T2_HD double t2_rsqrt_half_near(double a, double) { return 0.5 / sqrt(a); }
+T2_HD double t2_sqrt_from_h(double a, double) { return sqrt(a); }
 #endif
 
 template <typename T> T2_HD T t2_min(T a, T b) { return a < b ? a : b; }
@@ -350,15 +376,34 @@ T2_TABLE double t2_i0e_Bp[30] = {
 #ifndef T2_I0E_CHUNK
 #define T2_I0E_CHUNK 5  // coefficients per trip of the shared loop (30 = 2 x 15 = 3 x 10 = 5 x 6 = 6 x 5 = 10 x 3)
 #endif
-T2_HD void t2_i0e4_by_lane(const double* ax, bool lane_small, double* r) {
+// `near` (wave-uniform; the caller's guarantee that ax[1..3] lie within 2^-20, relative, of ax[0]): the reciprocals of the
+// (8, inf) series -- 32 / x before the recurrence, the division by sqrt(x) after it -- come from ONE reciprocal square root
+// (t2_sqrt_core_h of ax[0], a coupled Newton step to each of the others): h = 1 / (2 sqrt(x)) to 2^-50 gives 1 / x = (2h)^2
+// and 1 / sqrt(x) = 2h as the multipliers of the same quotient-and-residual steps, and sqrt(x) itself after the
+// recurrence as x * 2h and one residual correction.  Only the four h stay live across the loop.
+T2_HD void t2_i0e4_by_lane(const double* ax, bool lane_small, double* r, bool near = false) {
   constexpr int K = T2_I0E_CHUNK;
   static_assert(30 % K == 0, "the shared loop walks both 30-entry tables in whole chunks");
-  double z[4], b0[4], b1[4], b2[4];
-  T2_UNROLL
-  for (int j = 0; j < 4; ++j) {
-    const double za = ax[j] * 0.5 - 2.0, zb = t2_fdiv(32.0, ax[j]) - 2.0;
-    z[j] = lane_small ? za : zb;
-    b0[j] = 0.0; b1[j] = 0.0; b2[j] = 0.0;
+  double z[4], b0[4], b1[4], b2[4], hh[4];
+  if (near) {
+    (void)t2_sqrt_core_h(ax[0], hh[0]);
+    T2_UNROLL
+    for (int j = 1; j < 4; ++j) hh[j] = t2_rsqrt_half_near(ax[j], hh[0]);
+    T2_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      const double y = hh[j] + hh[j];
+      const double za = ax[j] * 0.5 - 2.0, zb = t2_div_by_rcp(32.0, ax[j], y * y) - 2.0;
+      z[j] = lane_small ? za : zb;
+      b0[j] = 0.0; b1[j] = 0.0; b2[j] = 0.0;
+    }
+  } else {
+    T2_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      const double za = ax[j] * 0.5 - 2.0, zb = t2_fdiv(32.0, ax[j]) - 2.0;
+      z[j] = lane_small ? za : zb;
+      b0[j] = 0.0; b1[j] = 0.0; b2[j] = 0.0;
+      hh[j] = 0.0;
+    }
   }
   double an[K], bn[K];
   T2_UNROLL
@@ -381,6 +426,16 @@ T2_HD void t2_i0e4_by_lane(const double* ax, bool lane_small, double* r) {
         b0[j] = T2_CLENSHAW(z[j], b1[j], b2[j], cc[q]);
       }
     }
+  }
+  if (near) {
+    T2_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      const double ra = 0.5 * (b0[j] - b2[j]);
+      const double y = hh[j] + hh[j];
+      const double rb = t2_div_by_rcp(ra, t2_sqrt_from_h(ax[j], hh[j]), y);
+      r[j] = lane_small ? ra : rb;
+    }
+    return;
   }
   T2_UNROLL
   for (int j = 0; j < 4; ++j) {
@@ -429,8 +484,8 @@ T2_HD double t2_log_lean(double x) {
 // wave-uniform.  A wave whose lanes all need the same series runs that series with scalar coefficients; a wave whose
 // lanes differ (practically always, see above) runs the shared 30-step loop; a wave in which some LANE has arguments on
 // both sides of 8 falls back to both series for everybody and a per-argument pick.  Whatever the path, every value is
-// produced by the operations of t2_i0e for its argument: the paths give identical bits.
-T2_HD void t2_log_i0e4(const double* x, double* out) {
+// produced by the operations of t2_i0e for its argument: the paths give identical bits.  `near`: see t2_i0e4_by_lane.
+T2_HD void t2_log_i0e4(const double* x, double* out, bool near = false) {
   double ax[4], z[4], ra[4], rb[4], r[4];
   bool small[4];
   T2_UNROLL
@@ -447,7 +502,7 @@ T2_HD void t2_log_i0e4(const double* x, double* out) {
 #endif
   const bool wave_small = T2_WAVE_ANY(any_small), wave_large = T2_WAVE_ANY(any_large);
   if (wave_small && wave_large && !T2_WAVE_ANY(any_small && any_large)) {
-    t2_i0e4_by_lane(ax, any_small, r);
+    t2_i0e4_by_lane(ax, any_small, r, near);
   } else {
     if (wave_small) {
       T2_UNROLL
@@ -529,13 +584,6 @@ T2_HD double t2_exp_res(double x, const double* cc) {
 inline void t2_exp_res_coefficients(double* cc) {  // 1/11!, 1/10!, ..., 1/2!
   double f = 1.0;
   for (int j = 2; j <= 11; ++j) { f *= j; cc[11 - j] = 1.0 / f; }
-}
-
-// a / b from r = 1/b (correctly rounded) with one residual correction: the correctly rounded quotient
-// except for rare last-bit cases, at three FMA-class operations instead of an IEEE division sequence
-T2_HD double t2_div_by_rcp(double a, double b, double r) {
-  const double q = a * r;
-  return fma(fma(-q, b, a), r, q);
 }
 
 // Mean signed residual from the float32 maps (utils/t2map_utils.py:62-89): float64 prediction

@@ -491,7 +491,7 @@ struct Lbfgsb {
       // the reference's steps are 1e-8 on k >= 550, sigma >= 2 and T2 >= 10 ms: 2^-36, 2^-28 and, at 300 ms, 2^-24)
       const double tol = 0x1p-22;
       const bool near = 2.0 * lb_abs(dx[0]) <= tol * lb_abs(x[0]) && 2.0 * lb_abs(dx[N - 1]) <= tol * lb_abs(x[N - 1]) &&
-                        2.0 * P.te_max * lb_abs(dx[1]) <= tol * (t2 * t2p);
+                        2.0 * P.te_max * lb_abs(dx[1]) <= tol * (t2 * t2p) && sg2 > 0.0;
       if (T2_WAVE_ANY(!near)) {
         // the rare way round: independent roots, one echo at a time in a real loop (compact code beside the straight-line
         // block below, whose registers it must not add to); same operations, same summation order (RowSums4)
@@ -552,6 +552,12 @@ struct Lbfgsb {
       // both quotients of a term share one reciprocal per noise level (1 / (2 sigma^2) is half of 1 / sigma^2, exactly)
       const double rs2 = t2_rcp_for_div(sg2), rsp2 = t2_rcp_for_div(sgp2);
       const bool legacy = P.numpy_legacy != 0;
+      // the four i0e arguments of an echo, (k E y / sigma^2 at the four points), within 2^-21 of each other: as for the square
+      // roots of the least-squares model above, checked on the parameters once per evaluation, for the whole wave
+      const double tol = 0x1p-22;
+      const bool near_lane = 2.0 * lb_abs(dx[0]) <= tol * lb_abs(x[0]) && 2.0 * lb_abs(dx[N - 1]) <= tol * lb_abs(x[N - 1]) &&
+                             2.0 * P.te_max * lb_abs(dx[1]) <= tol * (t2 * t2p);
+      const bool near = !T2_WAVE_ANY(!near_lane);
       RowSums4<NTE> sums;
       sums.init();
       T2_NOUNROLL
@@ -574,7 +580,7 @@ struct Lbfgsb {
         double xx[4], li[4], tm[4];
         T2_UNROLL
         for (int j = 0; j < 4; ++j) xx[j] = t2_div_by_rcp(m[j] * yd, j == 3 ? sgp2 : sg2, j == 3 ? rsp2 : rs2);
-        t2_log_i0e4(xx, li);
+        t2_log_i0e4(xx, li, near);
         T2_UNROLL
         for (int j = 0; j < 4; ++j) {
           const double a = rician_log_term(ly, j == 3 ? lsp2 : ls2, legacy);

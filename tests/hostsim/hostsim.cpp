@@ -252,3 +252,30 @@ extern "C" int hostsim_log_lean(const double* x, int64_t n, double* out) {
   for (int64_t v = 0; v < n; ++v) out[v] = t2_log_lean(x[v]);
   return 0;
 }
+
+// The shared-seed square roots of the evaluations (t2fit_lane.h `_seq`): plain FMA sequences, run here from a seed as coarse as
+// the hardware's reciprocal square root (float precision).  x[v] > 0 is the base argument, a[3v..3v+2] three arguments near it.
+// out_base / out_near: the sequences; out_h: sqrt from the refined h alone (the Rician lane's way round).
+extern "C" int hostsim_sqrt_near(const double* x, const double* a, int64_t n, double* out_base, double* out_near, double* out_h) {
+  for (int64_t v = 0; v < n; ++v) {
+    const double seed = (double)(1.0f / sqrtf((float)x[v]));
+    double h;
+    out_base[v] = t2_sqrt_from_seed_seq(x[v], seed, h);
+    for (int j = 0; j < 3; ++j) {
+      out_near[3 * v + j] = t2_sqrt_near_seq(a[3 * v + j], h);
+      out_h[3 * v + j] = t2_sqrt_from_h_seq(a[3 * v + j], t2_rsqrt_half_near_seq(a[3 * v + j], h));
+    }
+  }
+  return 0;
+}
+
+// t2_i0e4_by_lane with the reciprocals of the (8, inf) series taken from one shared reciprocal square root (`near`) against
+// the same loop with independent divisions and roots: groups of four nearby arguments on one side of 8.
+extern "C" int hostsim_i0e4_by_lane_near(const double* x, int64_t n, double* out, double* ref) {
+  for (int64_t v = 0; v < n; ++v) {
+    const bool lane_small = x[4 * v] <= 8.0;
+    t2_i0e4_by_lane(x + 4 * v, lane_small, out + 4 * v, true);
+    t2_i0e4_by_lane(x + 4 * v, lane_small, ref + 4 * v, false);
+  }
+  return 0;
+}

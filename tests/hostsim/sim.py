@@ -156,3 +156,25 @@ def log_lean(x):
     L.hostsim_log_lean.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
     assert L.hostsim_log_lean(x.ctypes.data, x.size, out.ctypes.data) == 0
     return out
+
+
+def sqrt_near(x, a):
+    """x: (n,) base arguments > 0, a: (n, 3) arguments near them -> (sqrt(x), sqrt(a), sqrt(a) from h alone) as the
+    FMA sequences of the kernels compute them from a float-precision reciprocal-root seed."""
+    L = lib()
+    x = np.ascontiguousarray(x, np.float64)
+    a = np.ascontiguousarray(a, np.float64)
+    base, near, from_h = np.empty_like(x), np.empty_like(a), np.empty_like(a)
+    L.hostsim_sqrt_near.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.hostsim_sqrt_near(x.ctypes.data, a.ctypes.data, len(x), base.ctypes.data, near.ctypes.data, from_h.ctypes.data) == 0
+    return base, near, from_h
+
+
+def i0e4_by_lane_near(x):
+    """x: (n, 4) float64 > 0, each row's arguments close together on one side of 8 -> (shared reciprocal root, independent)."""
+    L = lib()
+    x = np.ascontiguousarray(x, np.float64)
+    out, ref = np.empty_like(x), np.empty_like(x)
+    L.hostsim_i0e4_by_lane_near.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    assert L.hostsim_i0e4_by_lane_near(x.ctypes.data, len(x), out.ctypes.data, ref.ctypes.data) == 0
+    return out, ref

@@ -298,3 +298,36 @@ def test_rician_echo_loop_equals_the_statement_by_statement_objective(n_te, lega
             grad = [(obj(x + 1e-8 * np.eye(3)[j], te, row) - f0) / ((x[j] + 1e-8) - x[j]) for j in range(3)]
         assert np.isclose(out[0], f0, rtol=1e-6)  # np.log of a float32 array is not glibc's logf to the last bit: a constant shift
         assert np.allclose(out[1:], grad, rtol=1e-5, atol=2e-3)  # differences of nearly equal numbers: libm last bits
+
+
+def test_shared_seed_square_roots_are_the_correctly_rounded_ones():
+    """t2_sqrt_from_seed_seq / t2_sqrt_near_seq / t2_sqrt_from_h_seq (t2fit_lane.h): the FMA sequences behind the square roots of
+    an evaluation, here on the CPU from a float-precision seed (coarser than v_rsq_f64's): the base root, the roots of three
+    arguments within 2^-21 of the base argument started from the base's refined reciprocal root, and the root rebuilt from
+    the refined reciprocal root alone -- all bit for bit numpy's (IEEE) sqrt, on two million arguments across the
+    radicands' range, at the edge of the allowed distance, and at exact squares and their neighbours."""
+    rng = np.random.default_rng(5)
+    n = 500_000
+    x = 10.0 ** rng.uniform(-2, 10, n)
+    rel = np.concatenate([rng.uniform(-1, 1, (n // 2, 3)) * 1e-8, rng.uniform(-1, 1, (n - n // 2, 3)) * 2.0 ** -21])
+    a = x[:, None] * (1.0 + rel)
+    sq = np.floor(rng.uniform(1, 3e4, 2000)) ** 2  # exact squares: neighbours one ulp either side must round the right way
+    x = np.concatenate([x, sq])
+    a = np.concatenate([a, np.stack([np.nextafter(sq, 0), sq, np.nextafter(sq, np.inf)], axis=1)])
+    base, near, from_h = sim.sqrt_near(x, a)
+    assert np.array_equal(base, np.sqrt(x))
+    assert np.array_equal(near, np.sqrt(a))
+    assert np.array_equal(from_h, np.sqrt(a))
+
+
+def test_i0e_shared_reciprocal_root_equals_independent_divisions():
+    """t2_i0e4_by_lane(near=True) -- 32 / x and the division by sqrt(x) of the (8, inf) series through one shared reciprocal
+    square root -- against the same loop with its independent divisions and roots, bit for bit, for rows of four arguments
+    within 1e-8 (the reference's step) and within 2^-21 of each other on either side of 8."""
+    rng = np.random.default_rng(6)
+    base = np.concatenate([rng.uniform(8.0001, 60, 60000), 10.0 ** rng.uniform(1, 7, 60000), rng.uniform(1e-3, 7.9999, 20000)])
+    rel = np.where(rng.random((len(base), 1)) < 0.5, 1e-8, 2.0 ** -21) * rng.uniform(-1, 1, (len(base), 4))
+    rel[:, 0] = 0.0
+    x = base[:, None] * (1.0 + rel)
+    out, ref = sim.i0e4_by_lane_near(x)
+    assert np.array_equal(out, ref)
