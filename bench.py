@@ -499,7 +499,7 @@ def main():
                                             "drain of the launch before it, which it overlaps" if pipelined else None),
                          "bytes_per_voxel": bytes_per_voxel, "voxels_per_launch": n_vox,
                          "note": ("one streaming pass, HBM bound" if a.solver == "loglin" else
-                                  "the fit is float64 VALU-issue bound (about 4500 wave instructions per evaluation round; "
+                                  "the fit is float64 VALU-issue bound (about 3200 wave instructions per evaluation round of a wave, 2650 of them vector; "
                                   "eight one-wave workgroups per CU, two per SIMD), not HBM bound: see DESIGN.md section 6 "
                                   "and `alu`; bytes_per_voxel counts what THIS kernel moves (samples, mask, three maps)")},
         }
