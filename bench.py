@@ -203,6 +203,8 @@ def main():
         cpu = cpu_baseline(rows, te_c, a.fit, not a.no_prior, a.cpu_seconds)
         cpu_native = cpu_baseline_native(rows, te_c, a.fit, not a.no_prior, min(5.0, a.cpu_seconds))
     log("cpu baseline done" if cpu else "no cpu baseline")
+    # (the pool's host driver shares device memory between processes through dmabuf only; already exported there)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     lib = require_gpu()
     # T2FIT_BENCH_BACKEND=gloo is a REHEARSAL of the N > 1 control flow on a one-GPU box: every rank
     # uses cuda:0 and the gather is staged through the host.  Numbers from it mean nothing.

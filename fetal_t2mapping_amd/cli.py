@@ -566,6 +566,7 @@ def main(argv=None):
 
         backend = os.environ.get("T2FIT_CLI_BACKEND", "nccl")  # "gloo": rehearsal of the control flow without RCCL
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC between the ranks' processes (before HIP starts)
         if backend == "nccl":
             args.device = local_rank
             torch.cuda.set_device(local_rank)
