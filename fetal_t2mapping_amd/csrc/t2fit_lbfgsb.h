@@ -652,51 +652,52 @@ struct Lbfgsb {
     for (int i = 0; i < N; ++i)
       T2_UNROLL
       for (int j = 0; j < N; ++j) U[i][j] = i == j ? theta : 0.0;
-    double rp[N], yp[N];  // rp[1..N-1]: the current pair's ratios s_i / s_0 (rp[0] unused: it is the implicit 1)
+    // two register sets for the pairs, taken in turn: pair p is worked on in set p & 1 while pair p + 1 is fetched into
+    // the other one, whose last reader was pair p - 1 -- so the fetch can land where it will be read and no copy is
+    // needed (one set and a landing buffer cost five 64-bit moves per pair).  rp[.][1..N-1]: the pair's ratios
+    // s_i / s_0 (rp[.][0] unused: it is the implicit 1)
+    double rp[2][N], yp[2][N];
     T2_UNROLL
-    for (int i = 0; i < N; ++i) { rp[i] = 0.0; yp[i] = 0.0; }
+    for (int i = 0; i < N; ++i) { rp[0][i] = 0.0; yp[0][i] = 0.0; rp[1][i] = 0.0; yp[1][i] = 0.0; }
     int q = head;  // ring slot of pair p, stepped along instead of (head + p) % M per pair
     if (col > 0) {
       T2_UNROLL
-      for (int i = 1; i < N; ++i) rp[i] = hratio(q, i - 1);
+      for (int i = 1; i < N; ++i) rp[0][i] = hratio(q, i - 1);
       T2_UNROLL
-      for (int i = 0; i < N; ++i) yp[i] = hy(q, i);
+      for (int i = 0; i < N; ++i) yp[0][i] = hy(q, i);
     }
-    T2_UNROLL
-    for (int p = 0; p < M; ++p) {
-      if (p >= col) continue;
-      double rn[N], yn[N];
-      const int qn = p + 1 < col ? (q + 1 == M ? 0 : q + 1) : q;
-      q = qn;
-      rn[0] = 0.0;
-      T2_UNROLL
-      for (int i = 1; i < N; ++i) rn[i] = hratio(qn, i - 1);
-      T2_UNROLL
-      for (int i = 0; i < N; ++i) yn[i] = hy(qn, i);
-      // B s for s = (1, rp[1], rp[2]): the first column of B plus the ratios times the others
-      double bs[N];
-      T2_UNROLL
-      for (int i = 0; i < N; ++i) {
-        double a = U[0][i];  // = U[i][0] (symmetric; only j >= i is kept)
+    static_for<0, M>([&](auto PC) {
+      constexpr int p = decltype(PC)::value, cur = p & 1, nxt = cur ^ 1;
+      if (p < col) {
+        const int qn = p + 1 < col ? (q + 1 == M ? 0 : q + 1) : q;
+        q = qn;
         T2_UNROLL
-        for (int j = 1; j < N; ++j) a = fma(j >= i ? U[i][j] : U[j][i], rp[j], a);
-        bs[i] = a;
+        for (int i = 1; i < N; ++i) rp[nxt][i] = hratio(qn, i - 1);
+        T2_UNROLL
+        for (int i = 0; i < N; ++i) yp[nxt][i] = hy(qn, i);
+        // B s for s = (1, rp[1], rp[2]): the first column of B plus the ratios times the others
+        double bs[N];
+        T2_UNROLL
+        for (int i = 0; i < N; ++i) {
+          double a = U[0][i];  // = U[i][0] (symmetric; only j >= i is kept)
+          T2_UNROLL
+          for (int j = 1; j < N; ++j) a = fma(j >= i ? U[i][j] : U[j][i], rp[cur][j], a);
+          bs[i] = a;
+        }
+        double sbs = bs[0];
+        T2_UNROLL
+        for (int i = 1; i < N; ++i) sbs = fma(rp[cur][i], bs[i], sbs);
+        const double rsbs = t2_fast_rcp(sbs);
+        double tb[N];
+        T2_UNROLL
+        for (int i = 0; i < N; ++i) tb[i] = bs[i] * rsbs;
+        // (the ring holds y / sqrt(y's): the rank-one term y y' / (y's) needs no scaling here -- digest())
+        T2_UNROLL
+        for (int i = 0; i < N; ++i)
+          T2_UNROLL
+          for (int j = i; j < N; ++j) U[i][j] = fma(yp[cur][i], yp[cur][j], fma(-bs[i], tb[j], U[i][j]));
       }
-      double sbs = bs[0];
-      T2_UNROLL
-      for (int i = 1; i < N; ++i) sbs = fma(rp[i], bs[i], sbs);
-      const double rsbs = t2_fast_rcp(sbs);
-      double tb[N];
-      T2_UNROLL
-      for (int i = 0; i < N; ++i) tb[i] = bs[i] * rsbs;
-      // (the ring holds y / sqrt(y's): the rank-one term y y' / (y's) needs no scaling here -- digest())
-      T2_UNROLL
-      for (int i = 0; i < N; ++i)
-        T2_UNROLL
-        for (int j = i; j < N; ++j) U[i][j] = fma(yp[i], yp[j], fma(-bs[i], tb[j], U[i][j]));
-      T2_UNROLL
-      for (int i = 0; i < N; ++i) { rp[i] = rn[i]; yp[i] = yn[i]; }
-    }
+    });
     T2_UNROLL
     for (int i = 0; i < N; ++i)
       T2_UNROLL
