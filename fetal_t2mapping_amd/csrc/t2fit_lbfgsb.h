@@ -669,7 +669,12 @@ struct Lbfgsb {
     static_for<0, M>([&](auto PC) {
       constexpr int p = decltype(PC)::value, cur = p & 1, nxt = cur ^ 1;
       if (p < col) {
-        const int qn = p + 1 < col ? (q + 1 == M ? 0 : q + 1) : q;
+        // (with the whole ring in LDS the slot is stepped past the last pair too: that fetch reads a slot nobody uses and
+        // nobody uses what it returns, two instructions less per pair; with a global part it would pull a line that was
+        // never written all the way from HBM, and the next pair's wait for it costs the 2.4 % the register sets bring:
+        // profiles/r03_exp21_step_and_digest.txt)
+        const int step = q + 1 == M ? 0 : q + 1;
+        const int qn = (!kSplit || p + 1 < col) ? step : q;
         q = qn;
         T2_UNROLL
         for (int i = 1; i < N; ++i) rp[nxt][i] = hratio(qn, i - 1);
