@@ -453,8 +453,13 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
   for (;;) {
     // Refill in batches: the refill path (sample loads, seed / set-up) runs with only the idle lanes
     // active, so it is entered when at least refill_min lanes are idle (or nothing is running).
-    const unsigned long long need = __ballot(!busy);
+    unsigned long long need = __ballot(!busy);
     if (__popcll(need) >= refill_min || need == ~0ull) {
+      // (a loop of its own for the rare wave whose new voxels all ended at once -- samples that cannot be fitted -- so
+      // that the round below has ONE way in and the solver state one version per trip of the main loop: with a
+      // `continue` around the round the compiler kept the state in two register sets and copied it across, ~100 moves
+      // per round)
+      do {
       T2_BLK_T0(t_rf)
       // lanes that finished since the last refill hand in their results here, together, rather than one
       // or two at a time in the round they finished (the conversion and the stores are divergent code)
@@ -637,12 +642,12 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
         }
       }
       T2_BLK_END(c, 8, t_rf)
+      need = __ballot(!busy);
+      } while (need == ~0ull && (chunks_left || q_count != 0));
     }
-    if (__ballot(busy) == 0ull) {
-      if (!chunks_left && q_count == 0) break;
-      continue;
-    }
+    if (__ballot(busy) == 0ull) break;  // nothing running and nothing left to take
     if constexpr (A::kSplit) {
+#if defined(T2_PARK_SWITCH)
       // One round: every lane with a point to evaluate evaluates it (uniform code) and digests the result; lanes
       // whose line search has ended then run begin() (B, Cauchy point, subspace step, line-search set-up).
       // park_min > 1 holds those lanes back until that many of the wave are waiting (or no lane has anything to
@@ -667,6 +672,30 @@ __device__ __forceinline__ void persistent_fit(const LaneParams& P, const float*
           else if (pend == A::Solver::GO_TRIAL) parked = false;
         }
       }
+#else
+      // One round: every lane with a point to evaluate evaluates it (uniform code) and digests the result; lanes whose
+      // line search has ended then run begin_pass() (B, Cauchy point, subspace step, line-search set-up).  `parked`: the
+      // pass asked to be run again (memory dropped, line search could not start: rare) -- the lane comes back in the next
+      // round and skips the evaluation.  One region under `busy`, so that the solver state has one version per round.
+      // (-DT2_PARK_SWITCH: the round-2 form with T2FIT_PARK_MIN, which held the lanes that need begin_pass() back until
+      // that many of a wave were waiting; measured twice, never paid.)
+      (void)park_min;
+      if (busy) {
+        if (!parked) {
+          T2_BLK_T0(t_ev)
+          s.eval(c);
+          T2_BLK_END(c, 7, t_ev)
+          pend = s.digest(c);
+        }
+        if (pend == A::Solver::GO_BEGIN || pend == A::Solver::GO_FAIL) {
+          T2_BLK_T0(t_bg)
+          pend = s.begin_pass(c, pend);
+          T2_BLK_END(c, 9, t_bg)
+        }
+        parked = pend == A::Solver::GO_BEGIN || pend == A::Solver::GO_FAIL;
+        if (pend == A::Solver::GO_DONE) { busy = false; done = true; }
+      }
+#endif
     } else {
       if (busy) s.eval(c);
       if (busy && s.advance(c)) {
