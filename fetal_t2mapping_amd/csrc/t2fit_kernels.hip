@@ -339,10 +339,12 @@ template <int MODEL, int NTE = 0, bool GSPLIT = false> struct LbfgsbLane {
   // t2fit_lane.h t2_log_i0e4 -- it fits.)
   static constexpr bool kWaveWgOk = true;
 #ifndef T2_WAVE_HINT_2PAR
-#define T2_WAVE_HINT_2PAR 2
+#define T2_WAVE_HINT_2PAR 3
 #endif
-  // (two parameters: 240 B of pairs per lane would let ten waves share a CU, but three waves per SIMD means 168
-  // registers, 29-45 of the lane's spill to scratch, and 7.28 ms become 7.75: profiles/r02_exp50_2par_three_waves.txt)
+  // (two parameters: 240 B of pairs per lane let ten waves share a CU, three on two of its SIMDs: 168 registers.  In
+  // round 2 the lane spilled 29-45 registers at that limit and 7.28 ms became 7.75 -- profiles/r02_exp50_2par_three_waves.txt;
+  // since the main loop has one way into the round the lane needs 155-168 and nothing spills: 6.37 -> 5.96 ms at
+  // 256 x 256 x 180 x 6 TE, profiles/r03_exp23_2par_ten_waves.txt.  -DT2_WAVE_HINT_2PAR=2: eight waves.)
   static constexpr int kWaveWgHint = MODEL == T2FIT_MODEL_GAUSSIAN ? T2_WAVE_HINT_2PAR : kWaveHint;
   // lanes that must be idle before a wave refills.  Measured on MI355X at eight waves per CU (profiles/
   // r03_exp6_refill_take.txt), 256^3 x 8 TE: 1 -> 12.48 ms, 4 -> 12.13, 8 -> 12.03, 12 -> 12.20, 16 -> 12.42; the Rician
