@@ -405,6 +405,26 @@ T2_HD void t2_i0e4_by_lane(const double* ax, bool lane_small, double* r, bool ne
       hh[j] = 0.0;
     }
   }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(T2_I0E_SCALAR_COEFF)
+  // Each lane fetches ITS series' coefficients with vector loads from its own table pointer (two addresses per wave: two
+  // cache lines per load), a chunk ahead of their use.  Scalar loads of both tables and a per-lane pick cost six vector
+  // instructions per coefficient -- a 64-bit select between two scalar-register pairs is two moves and a v_cndmask per half,
+  // the constant bus feeds one scalar operand per instruction -- beside the twelve of the four recurrences
+  // (-DT2_I0E_SCALAR_COEFF: that form).
+  const double* tab = lane_small ? t2_i0e_A : t2_i0e_Bp;
+  double cn[K];
+  T2_UNROLL
+  for (int q = 0; q < K; ++q) cn[q] = tab[q];
+  T2_NOUNROLL
+  for (int it = 0; it < 30 / K; ++it) {
+    double cc[K];
+    T2_UNROLL
+    for (int q = 0; q < K; ++q) cc[q] = cn[q];
+    if (it + 1 < 30 / K) {
+      T2_UNROLL
+      for (int q = 0; q < K; ++q) cn[q] = tab[(it + 1) * K + q];
+    }
+#else
   double an[K], bn[K];
   T2_UNROLL
   for (int q = 0; q < K; ++q) { an[q] = t2_i0e_A[q]; bn[q] = t2_i0e_Bp[q]; }
@@ -417,6 +437,7 @@ T2_HD void t2_i0e4_by_lane(const double* ax, bool lane_small, double* r, bool ne
       T2_UNROLL
       for (int q = 0; q < K; ++q) { an[q] = t2_i0e_A[(it + 1) * K + q]; bn[q] = t2_i0e_Bp[(it + 1) * K + q]; }
     }
+#endif
     T2_UNROLL
     for (int q = 0; q < K; ++q) {
       T2_UNROLL
