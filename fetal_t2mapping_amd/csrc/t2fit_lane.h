@@ -412,18 +412,34 @@ T2_HD void t2_i0e4_by_lane(const double* ax, bool lane_small, double* r, bool ne
   // the constant bus feeds one scalar operand per instruction -- beside the twelve of the four recurrences
   // (-DT2_I0E_SCALAR_COEFF: that form).
   const double* tab = lane_small ? t2_i0e_A : t2_i0e_Bp;
-  double cn[K];
+  // two register sets for the coefficient chunks, taken in turn (the loads of the next chunk land where they will be read:
+  // no copies), so the loop makes two chunks per trip
+  static_assert((30 / K) % 2 == 0, "the shared loop takes the chunks two at a time");
+  double c0[K], c1[K];
   T2_UNROLL
-  for (int q = 0; q < K; ++q) cn[q] = tab[q];
-  T2_NOUNROLL
-  for (int it = 0; it < 30 / K; ++it) {
-    double cc[K];
+  for (int q = 0; q < K; ++q) c0[q] = tab[q];
+  auto chunk = [&](const double* cc) {
     T2_UNROLL
-    for (int q = 0; q < K; ++q) cc[q] = cn[q];
-    if (it + 1 < 30 / K) {
+    for (int q = 0; q < K; ++q) {
       T2_UNROLL
-      for (int q = 0; q < K; ++q) cn[q] = tab[(it + 1) * K + q];
+      for (int j = 0; j < 4; ++j) {
+        b2[j] = b1[j];
+        b1[j] = b0[j];
+        b0[j] = T2_CLENSHAW(z[j], b1[j], b2[j], cc[q]);
+      }
     }
+  };
+  T2_NOUNROLL
+  for (int it = 0; it < 30 / K; it += 2) {
+    T2_UNROLL
+    for (int q = 0; q < K; ++q) c1[q] = tab[(it + 1) * K + q];
+    chunk(c0);
+    if (it + 2 < 30 / K) {
+      T2_UNROLL
+      for (int q = 0; q < K; ++q) c0[q] = tab[(it + 2) * K + q];
+    }
+    chunk(c1);
+  }
 #else
   double an[K], bn[K];
   T2_UNROLL
@@ -437,7 +453,6 @@ T2_HD void t2_i0e4_by_lane(const double* ax, bool lane_small, double* r, bool ne
       T2_UNROLL
       for (int q = 0; q < K; ++q) { an[q] = t2_i0e_A[(it + 1) * K + q]; bn[q] = t2_i0e_Bp[(it + 1) * K + q]; }
     }
-#endif
     T2_UNROLL
     for (int q = 0; q < K; ++q) {
       T2_UNROLL
@@ -448,6 +463,7 @@ T2_HD void t2_i0e4_by_lane(const double* ax, bool lane_small, double* r, bool ne
       }
     }
   }
+#endif
   if (near) {
     T2_UNROLL
     for (int j = 0; j < 4; ++j) {
