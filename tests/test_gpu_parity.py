@@ -1065,6 +1065,15 @@ def test_large_volume_kernels_on_empty_masks_and_bad_samples(t2):
     keep[idx] = False
     for name in ("t2", "k", "sigma", "res", "nit", "status"):
         assert _bitwise_equal(getattr(got, name).reshape(-1)[keep], getattr(good, name).reshape(-1)[keep]), name
+    # every voxel ends the moment it is taken (a NaN in each row): the waves never have anything to evaluate and the refill
+    # block has to keep taking chunks by itself until the queue is dry -- large-volume kernel, generic kernel, LM
+    allbad = echoes.clone()
+    allbad[2, :] = float("nan")
+    for solver, cut in (("lbfgsb", n), ("lbfgsb", 300_000), ("lm", n)):
+        r = t2.fit_volume(allbad[:, :cut].contiguous().reshape(8, 1, 1, cut), full[:cut].contiguous(), te, "gaussian_rician", table,
+                          extras=True, solver=solver)
+        assert bool((r.status == _abi.ST_NONFINITE).all()) and bool((r.nit == 0).all())
+        assert bool((r.t2 == table["initial_guess"][1]).all())  # the clipped start point, as scipy returns it
 
 
 def test_config4_whole_uterus_slabs_equal_whole_volume(t2):
