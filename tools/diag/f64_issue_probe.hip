@@ -4,9 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
-enum { FMA, MUL, ADD, RCP, RSQ, CND, MOV, CVT, LDEXP, KINDS };
+enum { FMA, MUL, ADD, RCP, RSQ, CND, MOV, CVT, LDEXP, FMA_AS_MUL, FMA_AS_ADD, KINDS };
 static const char* kNames[KINDS] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_rcp_f64", "v_rsq_f64", "v_cndmask_b32", "v_mov_b64",
-                                    "v_cvt_f64_f32+back", "v_ldexp_f64"};
+                                    "v_cvt_f64_f32+back", "v_ldexp_f64", "v_fma_f64 as x*a (+ -0)", "v_fma_f64 as x+b (x * 1)"};
 
 template <int KIND> __global__ __launch_bounds__(256) void probe(double* out, int iters, double a, double b) {
   extern __shared__ double pad[];
@@ -29,6 +29,8 @@ template <int KIND> __global__ __launch_bounds__(256) void probe(double* out, in
       else if constexpr (KIND == MOV) { double t; asm volatile("v_mov_b64 %0, %1" : "=v"(t) : "v"(x[j])); x[j] = t; }
       else if constexpr (KIND == CVT) x[j] = (double)(float)x[j];
       else if constexpr (KIND == LDEXP) x[j] = __builtin_ldexp(x[j], (int)(i & 1));
+      else if constexpr (KIND == FMA_AS_MUL) x[j] = __builtin_fma(x[j], a, -0.0);
+      else if constexpr (KIND == FMA_AS_ADD) x[j] = __builtin_fma(x[j], 1.0, b);
     }
   }
   double s = 0;
@@ -38,14 +40,14 @@ template <int KIND> __global__ __launch_bounds__(256) void probe(double* out, in
 }
 
 template <int KIND> void run(double* out, hipEvent_t e0, hipEvent_t e1) {
-  const int iters = 4000;
+  const int iters = 40000;
   for (int per_cu : {1, 2}) {
     const size_t lds = per_cu == 1 ? 160 * 1024 - 256 : 80 * 1024 - 256;
     hipFuncSetAttribute((const void*)probe<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     float best = 1e9f;
     for (int rep = 0; rep < 4; ++rep) {
       hipEventRecord(e0);
-      hipLaunchKernelGGL(probe<KIND>, dim3(256 * per_cu), dim3(256), lds, 0, out, iters, 1.0000001, 0.5);
+      hipLaunchKernelGGL(probe<KIND>, dim3(256 * per_cu), dim3(256), lds, 0, out, iters, 1.00000001, 1e-9);
       hipEventRecord(e1);
       hipEventSynchronize(e1);
       float ms;
@@ -67,5 +69,6 @@ int main() {
   hipEventCreate(&e1);
   run<FMA>(out, e0, e1); run<MUL>(out, e0, e1); run<ADD>(out, e0, e1); run<RCP>(out, e0, e1); run<RSQ>(out, e0, e1);
   run<CND>(out, e0, e1); run<MOV>(out, e0, e1); run<CVT>(out, e0, e1); run<LDEXP>(out, e0, e1);
+  run<FMA_AS_MUL>(out, e0, e1); run<FMA_AS_ADD>(out, e0, e1); run<FMA>(out, e0, e1);
   return 0;
 }
